@@ -1,0 +1,108 @@
+/* pocs.h -- C ABI of libpocs.so, the MI355X-native collision-probability estimator.
+ *
+ * This is the drop-in boundary for the reference's OpenRAVE module `MCModule`
+ * (mcsimplugin/mcsimplugin.cpp:7-255) and the estimator it owns (`MCSimulator`,
+ * mcsimplugin/MCSimulator.h:93-930; `GM_Model`, mcsimplugin/GM_Model.h:34-126).
+ * Plain C types only; no exceptions cross this boundary.  Every function that returns `int`
+ * returns POCS_OK (0) or a negative POCS_E_* code; pocs_last_error() gives the text.
+ *
+ * One context = one GPU = one host thread at a time (the reference is single-threaded and takes
+ * the environment mutex per query, MCSimulator.h:272,282).  Contexts are independent.
+ * There is no CPU fallback: pocs_create fails when no HIP device is usable.
+ */
+#ifndef POCS_H
+#define POCS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POCS_OK 0
+#define POCS_E_ARG (-1)        /* bad argument / wrong token count                           */
+#define POCS_E_ORDER (-2)      /* command sent before the one it depends on (see below)      */
+#define POCS_E_STATE (-3)      /* run requested with incomplete configuration                */
+#define POCS_E_DEVICE (-4)     /* HIP error (text holds hipGetErrorString)                   */
+#define POCS_E_UNKNOWN_COMMAND (-5)
+#define POCS_E_BUFFER (-6)     /* caller buffer too small                                    */
+
+typedef struct pocs_ctx pocs_ctx;
+
+/* ---- lifetime: replaces CreateInterfaceValidated / MCModule ctor / DestroyPlugin ----------
+ * (mcsimplugin.cpp:12-45,236-255; MCSimulator ctor MCSimulator.h:139-156). `device` is the HIP
+ * ordinal. */
+int pocs_create(pocs_ctx** out, int device);
+void pocs_destroy(pocs_ctx* ctx);
+const char* pocs_last_error(const pocs_ctx* ctx);
+const char* pocs_version(void);
+
+/* ---- collision world: replaces the OpenRAVE environment + robot handed to the MCSimulator
+ * ctor and queried at MCSimulator.h:275,279.  boxes = M x {cx, cy, half_x, half_y, yaw_rad}. */
+int pocs_set_footprint(pocs_ctx* ctx, double dx, double dy, double half_x, double half_y);
+int pocs_set_obstacles(pocs_ctx* ctx, const double* boxes, int M);
+
+/* ---- typed twins of the setter commands (argument order = token order of the command) ---- */
+int pocs_set_alphas(pocs_ctx* ctx, const double* alphas, int n);            /* mcsimplugin.cpp:174-187 -> MCSimulator.h:224-230; n must be 4 */
+int pocs_set_q(pocs_ctx* ctx, double q);                                    /* :168-172 -> :232-235 */
+int pocs_set_num_landmarks(pocs_ctx* ctx, int n);                           /* :142-146 -> :208-212 */
+int pocs_set_landmarks(pocs_ctx* ctx, const double* xs_then_ys, int n);     /* :148-166 -> :214-218; needs set_num_landmarks first */
+int pocs_set_num_particles(pocs_ctx* ctx, long long n);                     /* :136-140 -> :182-186 */
+int pocs_set_initial_covariance(pocs_ctx* ctx, const double* row_major9);   /* :121-134 -> :176-180 */
+int pocs_set_path_length(pocs_ctx* ctx, int W);                             /* :115-119 -> :200-202 */
+int pocs_set_trajectory(pocs_ctx* ctx, const double* xs_ys_thetas, int W);  /* :83-97 -> :158-168 (also sets the initial mean); needs set_path_length first */
+int pocs_set_odometry(pocs_ctx* ctx, const double* r1s_trs_r2s, int Wm1);   /* :99-113 -> :170-174 */
+int pocs_set_num_gaussians(pocs_ctx* ctx, int K);                           /* :49-54 -> :188-192; 1..8 */
+int pocs_set_num_gmm_samples(pocs_ctx* ctx, long long n);                   /* :56-61 -> :194-198 */
+int pocs_set_seed(pocs_ctx* ctx, uint64_t seed);                            /* new: the reference seeds from the clock (MCSimulator.h:141, GM_Model.h:53-54) */
+
+/* ---- the two estimators ---------------------------------------------------------------- */
+int pocs_run_simulation(pocs_ctx* ctx, double* probability);       /* runSimulation,    mcsimplugin.cpp:75-81 -> MCSimulator.h:361-365 */
+int pocs_run_gmm_estimation(pocs_ctx* ctx, double* probability);   /* runGMMEstimation, mcsimplugin.cpp:66-72 -> MCSimulator.h:354-358 */
+
+/* ---- the text channel: same 15 command names and token grammar as MCModule's SendCommand
+ * (mcsimplugin.cpp:13-44) plus `setSeed`, `setFootprint`, `addObstacle`, `clearObstacles`,
+ * `help`.  `line` = "<name> <tokens...>".  The reply text (the probability for run*, "output"
+ * for MyCommand) is written NUL-terminated into out[cap]. */
+int pocs_send_command(pocs_ctx* ctx, const char* line, char* out, size_t cap);
+
+/* ---- options (ours) -------------------------------------------------------------------- */
+#define POCS_OPT_STORE_SAMPLES 1   /* 1 (default): GMM samples + flags are written to HBM (26 B/eval, auditable); 0: not stored */
+#define POCS_OPT_MC_FUSED 2        /* 0 (default): one launch per waypoint, particles streamed through HBM (56 B/eval); 1: whole roll-out in registers */
+#define POCS_OPT_USE_GRAPH 3       /* 1 (default): the per-run launch sequence is replayed from a hipGraph */
+#define POCS_OPT_PROFILE 4         /* 1: bracket the hot kernel with hipEvents (see pocs_get_kernel_time) */
+int pocs_set_option(pocs_ctx* ctx, int option, long long value);
+
+/* ---- sharding over GPUs (one process per GPU; the caller owns the collective) -----------
+ * A context evaluates global sample / particle indices [first, first+count) of the N configured;
+ * random draws are keyed by the GLOBAL index so results do not depend on the partition. */
+int pocs_set_shard(pocs_ctx* ctx, long long first, long long count);
+int pocs_set_stream(pocs_ctx* ctx, void* hip_stream);                 /* launch on this stream (e.g. torch's current stream) */
+
+/* GMM, one waypoint at a time: begin -> for w in 0..W-1 { step_local(w); <all-reduce SUM of
+ * moments_ptr(w), moments_len doubles>; } -> end.  step_local(w) first folds the (already
+ * reduced) moments of w-1 into the mixture, then samples + collides + reduces this shard. */
+int pocs_gmm_begin(pocs_ctx* ctx);
+int pocs_gmm_step_local(pocs_ctx* ctx, int waypoint);
+void* pocs_gmm_moments_ptr(pocs_ctx* ctx, int waypoint);              /* device pointer, f64[moments_len] */
+int pocs_gmm_moments_len(const pocs_ctx* ctx);
+int pocs_gmm_bind_moments(pocs_ctx* ctx, void* device_ptr, long long len_doubles);  /* optional: keep the [W][moments_len] moments in a caller-owned device buffer (e.g. a torch tensor handed to all_reduce); NULL unbinds */
+int pocs_gmm_end(pocs_ctx* ctx, double* probability);
+/* MC: the shard's count of particles that collided at least once (device-synchronous). */
+int pocs_mc_run_local(pocs_ctx* ctx, unsigned long long* collided);
+
+/* ---- results of the last run, for audits and parity tests ------------------------------- */
+int pocs_get_path_length(const pocs_ctx* ctx);
+int pocs_get_waypoint_probabilities(pocs_ctx* ctx, double* out, int cap);         /* `probabilities`, MCSimulator.h:660,678,817 */
+int pocs_get_moments(pocs_ctx* ctx, int waypoint, double* out, int cap);          /* K x 11: nFree nColl Sx Sy St Sxx Sxy Sxt Syy Syt Stt */
+int pocs_get_gmm_state(pocs_ctx* ctx, int waypoint, double* means3, double* covs9, double* weights);  /* the mixture sampled at `waypoint` */
+int pocs_get_host_chain(pocs_ctx* ctx, double* applied3, double* noisy3, double* z, double* mu3, double* cov9); /* per step i<W-1; z is L per step */
+long long pocs_copy_gmm_samples(pocs_ctx* ctx, double* xyt_aos, int16_t* flags, long long cap);  /* last waypoint's shard, 3 x n column-major like arma (x,y,theta triples) */
+long long pocs_copy_particles(pocs_ctx* ctx, double* xyt_aos, uint32_t* hits, long long cap);   /* mcparticles / particlecollisions, MCSimulator.h:105,108 */
+int pocs_get_kernel_time(pocs_ctx* ctx, double* total_ms, long long* launches);  /* hot-kernel time of the last run with POCS_OPT_PROFILE=1 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POCS_H */

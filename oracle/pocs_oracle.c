@@ -1,0 +1,655 @@
+/* pocs_oracle.c -- CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker the GPU path is compared against.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may build, load or call it; the product (libpocs.so) never
+ * links or includes anything under oracle/.
+ *
+ * What it restates (paths under /root/reference/mcsimplugin/ unless noted), in plain C99, scalar,
+ * one sample at a time, following the reference's own data flow (grouped samples, explicit free
+ * sets, Armadillo's cov/mean/normalise formulas):
+ *   MCSimulator.h:56-69     angleWrap / roundAngle              -> orc_wrap_angle
+ *   MCSimulator.h:413-431   prediction                          -> orc_prediction
+ *   MCSimulator.h:434-449   inverseOdometry                     -> orc_inverse_odometry
+ *   MCSimulator.h:495-513   generateM_EKF                       -> orc_generate_M
+ *   MCSimulator.h:453-468,517-529,868-881  V, G, EKFpredict     -> orc_ekf_predict
+ *   MCSimulator.h:368-381,470-492,883-929  observation, makeHRow, EKFupdate -> orc_ekf_update
+ *   MCSimulator.h:532-553,714-726          generateL + applied control      -> inside orc_host_chain
+ *   MCSimulator.h:391-410,383-387          sampleOdometry, sampleObservation -> inside orc_host_chain
+ *   MCSimulator.h:287-347   initParticles, moveParticles, checkParticleCollisions,
+ *                           getCollisionProportion              -> orc_run_mc
+ *   GM_Model.h:57-124       initModel, sampleNPoints, updateWeights
+ *   MCSimulator.h:570-642   truncateGMM (+ checkMatrixCollisions :241-253) -> orc_gmm_waypoint
+ *   MCSimulator.h:649-864   EKF_GaussProp driver loop, final 1 - prod(1 - p_i) -> orc_run_gmm
+ *   armadillo_bits/op_cov_meat.hpp:26-53, op_mean_meat.hpp:104-133,
+ *   op_normalise_meat.hpp:85-121, glue_mvnrnd_meat.hpp:92-147   -> orc_cov_mean, orc_normalise_l1, orc_chol3_lower
+ *
+ * What is NOT the reference's and is the build's own specification, restated
+ * here independently of the product sources:
+ *   - random streams: Philox4x32-10 + Box-Muller with the log / sincos kernels below (the
+ *     reference seeds Armadillo and std::default_random_engine from the clock, so it has no
+ *     reproducible stream, MCSimulator.h:141, GM_Model.h:53-54);
+ *   - the collision predicate: oriented footprint box vs oriented static boxes (the reference
+ *     calls OpenRAVE's CheckCollision, MCSimulator.h:279, which is not in its tree);
+ *   - degenerate truncation cases (a component with < 2 survivors is retired).
+ *
+ * Pinning status: see oracle/README.md -- pinned against the reference's fixtures where they
+ * exist (odometry.dat == inverseOdometry(trajectory.dat); Armadillo's fn_cov known answers;
+ * the compiled Armadillo / GM_Model.h pieces in oracle/_ref); the EKF chain and the OpenRAVE
+ * collision result are "parity unpinned" (MCSimulator.h needs <openrave/plugin.h>, absent here).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; fma() is always explicit).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_MAX_K 8
+#define ORC_MAX_L 32
+#define ORC_NMOM 11
+#define ORC_STATE 16
+
+/* ------------------------------------------------------------------------------------------ */
+/* random streams (build spec "POCS numerics v1")                                              */
+/* ------------------------------------------------------------------------------------------ */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int round = 0; round < 10; ++round) {
+    uint64_t prod0 = (uint64_t)c[0] * 0xD2511F53ull;
+    uint64_t prod1 = (uint64_t)c[2] * 0xCD9E8D57ull;
+    uint32_t hi0 = (uint32_t)(prod0 >> 32), lo0 = (uint32_t)prod0;
+    uint32_t hi1 = (uint32_t)(prod1 >> 32), lo1 = (uint32_t)prod1;
+    uint32_t t0 = hi1 ^ c[1] ^ k0;
+    uint32_t t2 = hi0 ^ c[3] ^ k1;
+    c[0] = t0; c[1] = lo1; c[2] = t2; c[3] = lo0;
+    k0 += 0x9E3779B9u;  /* golden ratio */
+    k1 += 0xBB67AE85u;  /* sqrt(3)-1 */
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+static void draw(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stream, uint32_t slot,
+                 uint32_t out[4]) {
+  uint32_t ctr[4], key[2];
+  ctr[0] = (uint32_t)(index & 0xffffffffu);
+  ctr[1] = (uint32_t)(index >> 32);
+  ctr[2] = waypoint;
+  ctr[3] = (stream << 16) | slot;
+  key[0] = (uint32_t)(seed & 0xffffffffu);
+  key[1] = (uint32_t)(seed >> 32);
+  orc_philox4x32_10(ctr, key, out);
+}
+
+/* natural log of a normal positive double: x = 2^k (1+f), sqrt(.5) < 1+f <= sqrt(2) */
+double orc_log(double x) {
+  static const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+  static const double G1 = 6.666666666666735130e-01, G2 = 3.999999999940941908e-01,
+                      G3 = 2.857142874366239149e-01, G4 = 2.222219843214978396e-01,
+                      G5 = 1.818357216161805012e-01, G6 = 1.531383769920937332e-01,
+                      G7 = 1.479819860511658591e-01;
+  uint64_t bits;
+  memcpy(&bits, &x, 8);
+  uint32_t high = (uint32_t)(bits >> 32);
+  int k = (int)(high >> 20) - 1023;
+  high &= 0x000fffffu;
+  uint32_t bump = (high + 0x95f64u) & 0x100000u;
+  high |= (bump ^ 0x3ff00000u);
+  k += (int)(bump >> 20);
+  bits = ((uint64_t)high << 32) | (bits & 0xffffffffull);
+  double m;
+  memcpy(&m, &bits, 8);
+  double f = m - 1.0;
+  double dk = (double)k;
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double w = z * z;
+  double even = w * fma(w, fma(w, G6, G4), G2);
+  double odd = z * fma(w, fma(w, fma(w, G7, G5), G3), G1);
+  double R = odd + even;
+  double hfsq = 0.5 * f * f;
+  return dk * LN2_HI - ((hfsq - fma(s, hfsq + R, dk * LN2_LO)) - f);
+}
+
+static double kernel_sin(double x) {
+  static const double S[6] = {-1.66666666666666324348e-01, 8.33333333332248946124e-03,
+                              -1.98412698298579493134e-04, 2.75573137070700676789e-06,
+                              -2.50507602534068634195e-08, 1.58969099521155010221e-10};
+  double z = x * x;
+  double p = S[5];
+  for (int i = 4; i >= 0; --i) p = fma(z, p, S[i]);
+  return fma(z * x, p, x);
+}
+static double kernel_cos(double x) {
+  static const double C[6] = {4.16666666666666019037e-02, -1.38888888888741095749e-03,
+                              2.48015872894767294178e-05, -2.75573143513906633035e-07,
+                              2.08757232129817482790e-09, -1.13596475577881948265e-11};
+  double z = x * x;
+  double p = C[5];
+  for (int i = 4; i >= 0; --i) p = fma(z, p, C[i]);
+  double hz = 0.5 * z;
+  double w = 1.0 - hz;
+  return w + (((1.0 - w) - hz) + (z * z) * p);
+}
+
+void orc_sincos(double x, double* s, double* c) {
+  double fn = rint(x * 6.36619772367581382433e-01);
+  int n = (int)fn;
+  double r = x - fn * 1.57079632673412561417e+00;
+  r = r - fn * 6.07710050630396597660e-11;
+  r = r - fn * 2.02226624879595063154e-21;
+  double ks = kernel_sin(r), kc = kernel_cos(r);
+  switch (n & 3) {
+    case 0: *s = ks; *c = kc; break;
+    case 1: *s = kc; *c = -ks; break;
+    case 2: *s = -ks; *c = -kc; break;
+    default: *s = -kc; *c = ks; break;
+  }
+}
+
+void orc_sincos_2pi_u32(uint32_t w, double* s, double* c) {
+  uint32_t oct = w >> 29, frac = w & 0x1fffffffu;
+  if (oct & 1u) frac = 0x20000000u - frac;
+  double phi = ((double)frac * (1.0 / 536870912.0)) * 7.85398163397448279e-01;
+  double ks = kernel_sin(phi), kc = kernel_cos(phi);
+  switch (oct) {
+    case 0: *s = ks; *c = kc; break;
+    case 1: *s = kc; *c = ks; break;
+    case 2: *s = kc; *c = -ks; break;
+    case 3: *s = ks; *c = -kc; break;
+    case 4: *s = -ks; *c = -kc; break;
+    case 5: *s = -kc; *c = -ks; break;
+    case 6: *s = -kc; *c = ks; break;
+    default: *s = -ks; *c = kc; break;
+  }
+}
+
+void orc_normal_pair(uint32_t w0, uint32_t w1, uint32_t w2, double* n0, double* n1) {
+  uint64_t a = (((uint64_t)w1 << 32) | w0) >> 11;
+  double u = (double)(a + 1) * (1.0 / 9007199254740992.0);
+  double radius = sqrt(-2.0 * orc_log(u));
+  double s, c;
+  orc_sincos_2pi_u32(w2, &s, &c);
+  *n0 = radius * c;
+  *n1 = radius * s;
+}
+
+void orc_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stream, double z[3],
+                 uint32_t* spare) {
+  uint32_t a[4], b[4];
+  double drop;
+  draw(seed, index, waypoint, stream, 0, a);
+  draw(seed, index, waypoint, stream, 1, b);
+  orc_normal_pair(a[0], a[1], a[2], &z[0], &z[1]);
+  orc_normal_pair(b[0], b[1], b[2], &z[2], &drop);
+  *spare = a[3];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* estimator math                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+#define ORC_PI 3.14159265358979323846 /* the reference's MPI macro, MCSimulator.h:43 */
+
+double orc_wrap_angle(double angle) { /* MCSimulator.h:56-65 */
+  if (!(fabs(angle) <= 1.0e9)) return angle; /* guard: build spec */
+  while (angle < 0) angle += 2 * ORC_PI;
+  while (angle > (2 * ORC_PI)) angle -= 2 * ORC_PI;
+  return angle;
+}
+
+void orc_prediction(const double state[3], const double cmd[3], double out[3]) { /* :413-431 */
+  double drot1 = cmd[0], dtrans = cmd[1], drot2 = cmd[2];
+  double s, c;
+  orc_sincos(state[2] + drot1, &s, &c);
+  out[0] = fma(dtrans, c, state[0]);
+  out[1] = fma(dtrans, s, state[1]);
+  out[2] = orc_wrap_angle(state[2] + drot1 + drot2);
+}
+
+void orc_inverse_odometry(const double p1[3], const double p2[3], double out[3]) { /* :434-449 */
+  double drot1 = atan2(p2[1] - p1[1], p2[0] - p1[0]) - p1[2];
+  drot1 = orc_wrap_angle(drot1);
+  double ex = p2[0] - p1[0], ey = p2[1] - p1[1];
+  double dtrans = sqrt(ex * ex + ey * ey);
+  double drot2 = p2[2] - p1[2] - drot1;
+  drot2 = orc_wrap_angle(drot2);
+  out[0] = drot1; out[1] = dtrans; out[2] = drot2;
+}
+
+void orc_generate_M(const double alphas[4], const double cmd[3], double Mdiag[3]) { /* :495-513 */
+  double r1 = cmd[0], tr = cmd[1], r2 = cmd[2];
+  Mdiag[0] = alphas[0] * (r1 * r1) + alphas[1] * (tr * tr);
+  Mdiag[1] = alphas[2] * (tr * tr) + alphas[3] * (r1 * r1) + alphas[3] * (r2 * r2);
+  Mdiag[2] = alphas[0] * (r2 * r2) + alphas[1] * (tr * tr);
+}
+
+typedef double mat3[3][3];
+
+static void mm(mat3 A, mat3 B, mat3 C) { /* C = A B, inner sum left to right */
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[i][j] = (A[i][0] * B[0][j] + A[i][1] * B[1][j]) + A[i][2] * B[2][j];
+}
+static void mmt(mat3 A, mat3 B, mat3 C) { /* C = A B^T */
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[i][j] = (A[i][0] * B[j][0] + A[i][1] * B[j][1]) + A[i][2] * B[j][2];
+}
+
+/* EKFpredict :868-881.  Sigma, predSigma row-major 9. */
+void orc_ekf_predict(const double mu[3], const double Sigma[9], const double u[3],
+                     const double Mdiag[3], double predMu[3], double predSigma[9]) {
+  double s, c;
+  orc_sincos(mu[2] + u[0], &s, &c);
+  mat3 G = {{1, 0, -u[1] * s}, {0, 1, u[1] * c}, {0, 0, 1}};            /* :517-529 */
+  mat3 V = {{-u[1] * s, c, 0}, {u[1] * c, s, 0}, {1, 0, 1}};            /* :453-468, as written */
+  mat3 M = {{Mdiag[0], 0, 0}, {0, Mdiag[1], 0}, {0, 0, Mdiag[2]}};
+  mat3 S, VM, R, GS, GSG;
+  memcpy(S, Sigma, sizeof S);
+  mm(V, M, VM);
+  mmt(VM, V, R);                                                         /* R = V M V^T */
+  mm(G, S, GS);
+  mmt(GS, G, GSG);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) predSigma[3 * i + j] = GSG[i][j] + R[i][j];
+  predMu[0] = fma(u[1], c, mu[0]);                                       /* prediction(mu,u) */
+  predMu[1] = fma(u[1], s, mu[1]);
+  predMu[2] = orc_wrap_angle(mu[2] + u[0] + u[2]);
+}
+
+/* EKFupdate :883-929, in place on (mu, Sigma); landmarks lx,ly; measurements z[L]. */
+void orc_ekf_update(double mu[3], double Sigma[9], const double* z, int L, const double* lx,
+                    const double* ly, double Q) {
+  for (int lid = 0; lid < L; ++lid) {
+    double diff0 = mu[0] - lx[lid], diff1 = mu[1] - ly[lid];           /* makeHRow :470-492 */
+    double q = diff0 * diff0 + diff1 * diff1;
+    double root = sqrt(q);
+    double H[3] = {-(lx[lid] - mu[0]) / root, -(ly[lid] - mu[1]) / root, 0.0};
+    mat3 P;
+    memcpy(P, Sigma, sizeof P);
+    double HP0 = H[0] * P[0][0] + H[1] * P[1][0];                      /* H * Sigma (H[2] = 0) */
+    double HP1 = H[0] * P[0][1] + H[1] * P[1][1];
+    double S = (HP0 * H[0] + HP1 * H[1]) + Q;                           /* :902 */
+    double Sinv = 1.0 / S;                                              /* 1x1 .i() */
+    double K[3];
+    for (int i = 0; i < 3; ++i) K[i] = (P[i][0] * H[0] + P[i][1] * H[1]) * Sinv;   /* :906 */
+    double zhat = root;                                                 /* observation :368-381 */
+    double innovation = z[lid] - zhat;
+    for (int i = 0; i < 3; ++i) mu[i] = mu[i] + K[i] * innovation;      /* :919 */
+    mat3 A, N;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) A[i][j] = (i == j ? 1.0 : 0.0) - K[i] * H[j];
+    A[0][2] = 0.0; A[1][2] = 0.0; A[2][2] = 1.0;                        /* H[2] == 0 exactly */
+    mm(A, P, N);                                                        /* :921 */
+    memcpy(Sigma, N, sizeof N);
+  }
+}
+
+/* chol(C,"lower"), lower triangle only (LAPACK potrf semantics). L = l00 l10 l11 l20 l21 l22 */
+int orc_chol3_lower(const double C[9], double L[6]) {
+  if (!(C[0] > 0.0)) return 0;
+  double l00 = sqrt(C[0]);
+  double l10 = C[3] / l00, l20 = C[6] / l00;
+  double t = C[4] - l10 * l10;
+  if (!(t > 0.0)) return 0;
+  double l11 = sqrt(t);
+  double l21 = (C[7] - l20 * l10) / l11;
+  double v = (C[8] - l20 * l20) - l21 * l21;
+  if (!(v > 0.0)) return 0;
+  L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = sqrt(v);
+  return 1;
+}
+
+/* arma::mean(X,1) and arma::cov(X.t()) for X = 3 x n given as n rows of 3 (op_mean_meat.hpp:104-133,
+ * op_cov_meat.hpp:26-53): acc = sum(A); out = A^T A; out -= acc^T acc / N; out /= (N-1). */
+void orc_cov_mean(const double* rows, long long n, double mean[3], double cov[9]) {
+  double acc[3] = {0, 0, 0};
+  double ata[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (long long r = 0; r < n; ++r) {
+    const double* p = rows + 3 * r;
+    for (int i = 0; i < 3; ++i) {
+      acc[i] += p[i];
+      for (int j = 0; j < 3; ++j) ata[i][j] += p[i] * p[j];
+    }
+  }
+  double N = (double)n;
+  double norm_val = (n > 1) ? (N - 1.0) : 1.0;
+  for (int i = 0; i < 3; ++i) {
+    mean[i] = acc[i] / N;
+    for (int j = 0; j < 3; ++j) cov[3 * i + j] = (ata[i][j] - (acc[i] * acc[j]) / N) / norm_val;
+  }
+}
+
+/* normalise(row, 1): divide by the L1 norm; zero norm divides by 1 (op_normalise_meat.hpp:107-121) */
+void orc_normalise_l1(const double* in, int n, double* out) {
+  double norm = 0.0;
+  for (int i = 0; i < n; ++i) norm += fabs(in[i]);
+  double d = (norm != 0.0) ? norm : 1.0;
+  for (int i = 0; i < n; ++i) out[i] = in[i] / d;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* collision predicate (build spec): footprint box vs static boxes, separating axes            */
+/* fp = {dx, dy, hx, hy}; boxes = M x {cx, cy, hx, hy, yaw}                                      */
+/* ------------------------------------------------------------------------------------------ */
+int orc_collides(double x, double y, double th, const double fp[4], const double* boxes, int M) {
+  double s, c;
+  orc_sincos(th, &s, &c);
+  double px = x + fma(c, fp[0], -(s * fp[1]));
+  double py = y + fma(s, fp[0], c * fp[1]);
+  double rx = fp[2], ry = fp[3];
+  double rr = sqrt(rx * rx + ry * ry);
+  int hit = 0;
+  for (int m = 0; m < M; ++m) {
+    const double* b = boxes + 5 * m;
+    double bs, bc;
+    orc_sincos(b[4], &bs, &bc);
+    double hx = b[2], hy = b[3];
+    double reach_x = (hx * fabs(bc) + hy * fabs(bs)) + rr;   /* inflated world AABB */
+    double reach_y = (hx * fabs(bs) + hy * fabs(bc)) + rr;
+    double ddx = b[0] - px, ddy = b[1] - py;
+    if (fabs(ddx) > reach_x || fabs(ddy) > reach_y) continue;
+    double cr = fabs(fma(c, bc, s * bs));
+    double sr = fabs(fma(s, bc, -(c * bs)));
+    double in_robot_1 = fma(ddx, c, ddy * s), in_robot_2 = fma(ddy, c, -(ddx * s));
+    double in_box_1 = fma(ddx, bc, ddy * bs), in_box_2 = fma(ddy, bc, -(ddx * bs));
+    if (fabs(in_robot_1) > rx + fma(hx, cr, hy * sr)) continue;
+    if (fabs(in_robot_2) > ry + fma(hx, sr, hy * cr)) continue;
+    if (fabs(in_box_1) > hx + fma(rx, cr, ry * sr)) continue;
+    if (fabs(in_box_2) > hy + fma(rx, sr, ry * cr)) continue;
+    hit = 1;
+  }
+  return hit;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* configuration shared by the run functions                                                   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+  double alphas[4];
+  double Q;
+  int L;
+  int W;
+  int K;
+  int M;
+  double lx[ORC_MAX_L], ly[ORC_MAX_L];
+  double cov0[9];
+  double fp[4];
+  const double* traj;   /* 3 x W by component  (setTrajectory layout, mcsimplugin.cpp:83-97)  */
+  const double* odom;   /* 3 x (W-1) by component (mcsimplugin.cpp:99-113)                    */
+  const double* boxes;  /* M x 5 */
+} orc_config;
+
+static double chain_normal(uint64_t seed, int step, int k) {
+  uint32_t w[4];
+  double a, b;
+  draw(seed, (uint64_t)step, 0, 1 /* chain stream */, (uint32_t)(k / 2), w);
+  orc_normal_pair(w[0], w[1], w[2], &a, &b);
+  return (k % 2) ? b : a;
+}
+
+/* EKF_GaussProp's particle-independent part, MCSimulator.h:692-800.  Per step i < W-1 writes
+ * applied[3i..], Mdiag[3i..], noisy[3i..], z[L*i..], mu[3i..], cov[9i..] (any may be NULL). */
+int orc_host_chain(const orc_config* cfg, uint64_t seed, double* applied, double* Mdiag,
+                   double* noisy, double* z, double* mu_out, double* cov_out) {
+  int W = cfg->W, L = cfg->L;
+  double mu[3] = {cfg->traj[0], cfg->traj[W], cfg->traj[2 * W]};     /* initialmu = col 0, :164 */
+  double cov[9];
+  memcpy(cov, cfg->cov0, sizeof cov);
+  double realstate[3] = {mu[0], mu[1], mu[2]};
+  for (int i = 0; i < W - 1; ++i) {
+    double control[3], nominal[3], goal[3];
+    for (int j = 0; j < 3; ++j) {
+      control[j] = cfg->odom[j * (W - 1) + i];
+      nominal[j] = cfg->traj[j * W + i];
+      goal[j] = cfg->traj[j * W + i + 1];
+    }
+    double Md[3];
+    orc_generate_M(cfg->alphas, control, Md);                            /* :701 nominal control */
+    double urequired[3], appliedc[3];
+    orc_inverse_odometry(mu, goal, urequired);                           /* generateL :537 */
+    for (int j = 0; j < 3; ++j) {
+      double xhat = mu[j] - nominal[j];
+      double ubar = urequired[j] - control[j];
+      double Ljj = ubar / (xhat != 0 ? xhat : 0.1);                      /* :548-550 */
+      appliedc[j] = control[j] + Ljj * xhat;                             /* :722-726 */
+    }
+    double predMu[3], predSigma[9];
+    orc_ekf_predict(mu, cov, appliedc, Md, predMu, predSigma);           /* :746 */
+    double a1 = cfg->alphas[0], a2 = cfg->alphas[1], a3 = cfg->alphas[2], a4 = cfg->alphas[3];
+    double r1 = appliedc[0], tr = appliedc[1], r2 = appliedc[2];
+    double var0 = a1 * (r1 * r1) + a2 * (tr * tr);                       /* sampleOdometry :403-405 */
+    double var1 = a3 * (tr * tr) + a4 * ((r1 * r1) + (r2 * r2));
+    double var2 = a1 * (r2 * r2) + a2 * (tr * tr);
+    double noisyc[3];
+    noisyc[0] = r1 + chain_normal(seed, i, 0) * sqrt(var0);              /* sampleNormal :51-53 */
+    noisyc[1] = tr + chain_normal(seed, i, 1) * sqrt(var1);
+    noisyc[2] = r2 + chain_normal(seed, i, 2) * sqrt(var2);
+    double nextstate[3];
+    orc_prediction(realstate, noisyc, nextstate);                        /* :407 */
+    memcpy(realstate, nextstate, sizeof realstate);
+    double obs[ORC_MAX_L];
+    for (int l = 0; l < L; ++l) {                                        /* :786-789 */
+      double ex = realstate[0] - cfg->lx[l], ey = realstate[1] - cfg->ly[l];
+      double distance = sqrt(ex * ex + ey * ey);
+      obs[l] = distance + (0.0 + chain_normal(seed, i, 3 + l) * sqrt(cfg->Q));
+    }
+    orc_ekf_update(predMu, predSigma, obs, L, cfg->lx, cfg->ly, cfg->Q);  /* :797 */
+    memcpy(mu, predMu, sizeof mu);
+    memcpy(cov, predSigma, sizeof cov);
+    if (applied) memcpy(applied + 3 * i, appliedc, sizeof appliedc);
+    if (Mdiag) memcpy(Mdiag + 3 * i, Md, sizeof Md);
+    if (noisy) memcpy(noisy + 3 * i, noisyc, sizeof noisyc);
+    if (z) memcpy(z + (size_t)L * i, obs, (size_t)L * sizeof(double));
+    if (mu_out) memcpy(mu_out + 3 * i, mu, sizeof mu);
+    if (cov_out) memcpy(cov_out + 9 * i, cov, sizeof cov);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* MC path: runSimulation, MCSimulator.h:361-365 -> EKF_GaussProp("MC")                          */
+/* Particles [first, first+count) of the N configured.  hits (count) and final particles       */
+/* (count x 3, x y theta triples = the reference's 3 x N column-major) may be NULL.            */
+/* Returns the number of particles with hits > 0 (getCollisionProportion's numerator).         */
+/* ------------------------------------------------------------------------------------------ */
+long long orc_run_mc(const orc_config* cfg, uint64_t seed, long long first, long long count,
+                     uint32_t* hits_out, double* particles_out) {
+  int W = cfg->W;
+  double* noisy = (double*)malloc(sizeof(double) * 3 * (size_t)(W > 1 ? W - 1 : 1));
+  orc_host_chain(cfg, seed, NULL, NULL, noisy, NULL, NULL, NULL);
+  double L0[6];
+  if (!orc_chol3_lower(cfg->cov0, L0)) { free(noisy); return -1; }
+  double mu0[3] = {cfg->traj[0], cfg->traj[W], cfg->traj[2 * W]};
+  long long collided = 0;
+  for (long long i = 0; i < count; ++i) {
+    double zz[3];
+    uint32_t spare;
+    orc_normal3(seed, (uint64_t)(first + i), 0, 2 /* mc-init stream */, zz, &spare);
+    double p[3];                                                         /* initParticles :287-297 */
+    p[0] = fma(L0[0], zz[0], mu0[0]);
+    p[1] = fma(L0[2], zz[1], fma(L0[1], zz[0], mu0[1]));
+    p[2] = fma(L0[5], zz[2], fma(L0[4], zz[1], fma(L0[3], zz[0], mu0[2])));
+    uint32_t h = orc_collides(p[0], p[1], p[2], cfg->fp, cfg->boxes, cfg->M) ? 1u : 0u;   /* :668 */
+    for (int s = 0; s < W - 1; ++s) {                                    /* :760-761 */
+      double q[3];
+      orc_prediction(p, noisy + 3 * s, q);                               /* moveParticles :300-322 */
+      memcpy(p, q, sizeof p);
+      if (orc_collides(p[0], p[1], p[2], cfg->fp, cfg->boxes, cfg->M)) ++h;
+    }
+    if (h > 0) ++collided;
+    if (hits_out) hits_out[i] = h;
+    if (particles_out) memcpy(particles_out + 3 * i, p, sizeof p);
+  }
+  free(noisy);
+  return collided;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* GMM path                                                                                    */
+/* state (per component, ORC_STATE doubles): mean[3] cov[9] weight alive pad pad               */
+/* moments (per component, ORC_NMOM): nFree nColl Sx Sy St Sxx Sxy Sxt Syy Syt Stt             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* One waypoint's sampleNPoints + checkMatrixCollisions + sums for samples [first, first+count):
+ * GM_Model.h:83-116 and MCSimulator.h:582-611.  The component of a sample is one categorical
+ * draw per sample (GM_Model.h:89-93 draws N of them and counts; drawing it next to the sample
+ * gives the same joint law and keeps a sample's randomness a function of its index).
+ * samples_out (count x 3), flags_out (count), comp_out (count) optional. */
+int orc_gmm_waypoint(const orc_config* cfg, uint64_t seed, int waypoint, const double* state,
+                     long long first, long long count, double* moments, double* samples_out,
+                     int16_t* flags_out, int8_t* comp_out) {
+  int K = cfg->K;
+  double chol[ORC_MAX_K][6];
+  double table[ORC_MAX_K];
+  int last_alive = -1;
+  double running = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const double* st = state + k * ORC_STATE;
+    memset(chol[k], 0, sizeof chol[k]);
+    if (st[13] != 0.0) orc_chol3_lower(st + 3, chol[k]);
+    if (st[13] != 0.0 && st[12] > 0.0) last_alive = k;
+  }
+  for (int k = 0; k < K; ++k) {
+    running += state[k * ORC_STATE + 12];
+    table[k] = (k >= last_alive) ? 2.0 : running;
+  }
+  /* the reference keeps one matrix of points per component (GM_Model.h:99-107) and takes
+   * mean / cov of the free columns afterwards (MCSimulator.h:592-598); do the same. */
+  double* free_pts[ORC_MAX_K];
+  long long nfree[ORC_MAX_K], ncoll[ORC_MAX_K];
+  for (int k = 0; k < K; ++k) {
+    free_pts[k] = (double*)malloc(sizeof(double) * 3 * (size_t)(count > 0 ? count : 1));
+    nfree[k] = 0; ncoll[k] = 0;
+  }
+  for (long long i = 0; i < count; ++i) {
+    double zz[3];
+    uint32_t spare;
+    orc_normal3(seed, (uint64_t)(first + i), (uint32_t)waypoint, 3 /* gmm stream */, zz, &spare);
+    double uc = ((double)spare + 0.5) * (1.0 / 4294967296.0);
+    int k = 0;
+    for (int j = 0; j < K - 1; ++j) if (table[j] < uc) ++k;
+    const double* st = state + k * ORC_STATE;
+    const double* Lk = chol[k];
+    double pt[3];                                                       /* mvnrnd: D*z + M */
+    pt[0] = fma(Lk[0], zz[0], st[0]);
+    pt[1] = fma(Lk[2], zz[1], fma(Lk[1], zz[0], st[1]));
+    pt[2] = fma(Lk[5], zz[2], fma(Lk[4], zz[1], fma(Lk[3], zz[0], st[2])));
+    int hit = orc_collides(pt[0], pt[1], pt[2], cfg->fp, cfg->boxes, cfg->M);
+    if (hit) ++ncoll[k];
+    else { memcpy(free_pts[k] + 3 * nfree[k], pt, sizeof pt); ++nfree[k]; }
+    if (samples_out) memcpy(samples_out + 3 * i, pt, sizeof pt);
+    if (flags_out) flags_out[i] = (int16_t)hit;
+    if (comp_out) comp_out[i] = (int8_t)k;
+  }
+  for (int k = 0; k < K; ++k) {
+    double* m = moments + k * ORC_NMOM;
+    double sx = 0, sy = 0, st = 0, sxx = 0, sxy = 0, sxt = 0, syy = 0, syt = 0, stt = 0;
+    for (long long r = 0; r < nfree[k]; ++r) {
+      const double* p = free_pts[k] + 3 * r;
+      sx += p[0]; sy += p[1]; st += p[2];
+      sxx += p[0] * p[0]; sxy += p[0] * p[1]; sxt += p[0] * p[2];
+      syy += p[1] * p[1]; syt += p[1] * p[2]; stt += p[2] * p[2];
+    }
+    m[0] = (double)nfree[k]; m[1] = (double)ncoll[k];
+    m[2] = sx; m[3] = sy; m[4] = st; m[5] = sxx; m[6] = sxy; m[7] = sxt; m[8] = syy; m[9] = syt; m[10] = stt;
+    free(free_pts[k]);
+  }
+  return 0;
+}
+
+/* truncateGMM's tail + the per-component EKF of the next step: MCSimulator.h:597-629, :766-771,
+ * :804-812.  prev/next: K x ORC_STATE; moments: K x ORC_NMOM (global sums) or NULL at waypoint 0;
+ * u, Md, z: applied control, diag(M), observations of the step leading to this waypoint. */
+void orc_gmm_advance(const orc_config* cfg, const double* prev, const double* moments,
+                     const double* u, const double* Md, const double* z, double* next) {
+  int K = cfg->K;
+  double raw[ORC_MAX_K] = {0};
+  for (int k = 0; k < K; ++k) {
+    const double* p = prev + k * ORC_STATE;
+    double* o = next + k * ORC_STATE;
+    memcpy(o, p, sizeof(double) * ORC_STATE);
+    raw[k] = p[12];
+    if (!moments) continue;
+    raw[k] = 0.0;
+    if (p[13] == 0.0) { o[12] = 0.0; continue; }
+    const double* m = moments + k * ORC_NMOM;
+    double n = m[0];
+    if (!(n >= 2.0)) { o[13] = 0.0; o[12] = 0.0; continue; }            /* retired: build spec */
+    double mean[3] = {m[2] / n, m[3] / n, m[4] / n};                     /* mean(free,1) :597 */
+    double nm1 = n - 1.0;
+    double cov[9];                                                       /* cov(free^T) :598 */
+    cov[0] = (m[5] - (m[2] * m[2]) / n) / nm1;
+    cov[1] = (m[6] - (m[2] * m[3]) / n) / nm1;
+    cov[2] = (m[7] - (m[2] * m[4]) / n) / nm1;
+    cov[4] = (m[8] - (m[3] * m[3]) / n) / nm1;
+    cov[5] = (m[9] - (m[3] * m[4]) / n) / nm1;
+    cov[8] = (m[10] - (m[4] * m[4]) / n) / nm1;
+    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+    double pm[3], pc[9];
+    orc_ekf_predict(mean, cov, u, Md, pm, pc);                           /* :769 */
+    orc_ekf_update(pm, pc, z, cfg->L, cfg->lx, cfg->ly, cfg->Q);         /* :806 */
+    memcpy(o, pm, sizeof pm);
+    memcpy(o + 3, pc, sizeof pc);
+    raw[k] = n;                                                          /* collisionCounts(1,k) :611 */
+  }
+  for (int k = 0; k < K; ++k) {                                          /* mvnrnd needs chol */
+    double* o = next + k * ORC_STATE;
+    double Ltmp[6];
+    if (o[13] != 0.0 && !orc_chol3_lower(o + 3, Ltmp)) { o[13] = 0.0; raw[k] = 0.0; }
+  }
+  if (moments) {
+    double w[ORC_MAX_K];
+    orc_normalise_l1(raw, K, w);                                         /* :618-629 */
+    for (int k = 0; k < K; ++k) next[k * ORC_STATE + 12] = w[k];
+  } else {
+    for (int k = 0; k < K; ++k) next[k * ORC_STATE + 12] = raw[k];
+  }
+}
+
+void orc_gmm_initial_state(const orc_config* cfg, double* state) {     /* initGMM / initModel */
+  int W = cfg->W;
+  for (int k = 0; k < cfg->K; ++k) {
+    double* s = state + k * ORC_STATE;
+    memset(s, 0, sizeof(double) * ORC_STATE);
+    s[0] = cfg->traj[0]; s[1] = cfg->traj[W]; s[2] = cfg->traj[2 * W];
+    memcpy(s + 3, cfg->cov0, sizeof(double) * 9);
+    s[12] = 1.0 / cfg->K;
+    s[13] = 1.0;
+  }
+}
+
+/* runGMMEstimation (MCSimulator.h:354-358 -> EKF_GaussProp("GMM") :649-864), all N samples.
+ * probs_out[W], moments_out[W*K*11], states_out[W*K*16] optional.
+ * last_samples (N x 3) / last_flags (N): the final waypoint's samples, optional. */
+double orc_run_gmm(const orc_config* cfg, uint64_t seed, long long N, double* probs_out,
+                   double* moments_out, double* states_out, double* last_samples,
+                   int16_t* last_flags) {
+  int W = cfg->W, K = cfg->K, L = cfg->L;
+  size_t steps = (size_t)(W > 1 ? W - 1 : 1);
+  double* applied = (double*)malloc(sizeof(double) * 3 * steps);
+  double* Md = (double*)malloc(sizeof(double) * 3 * steps);
+  double* z = (double*)malloc(sizeof(double) * (size_t)(L > 0 ? L : 1) * steps);
+  orc_host_chain(cfg, seed, applied, Md, NULL, z, NULL, NULL);
+  double state[ORC_MAX_K * ORC_STATE], next[ORC_MAX_K * ORC_STATE], mom[ORC_MAX_K * ORC_NMOM];
+  orc_gmm_initial_state(cfg, state);
+  orc_gmm_advance(cfg, state, NULL, NULL, NULL, NULL, next);
+  memcpy(state, next, sizeof state);
+  double prod = 1.0;
+  for (int w = 0; w < W; ++w) {
+    int last = (w == W - 1);
+    if (states_out) memcpy(states_out + (size_t)w * K * ORC_STATE, state, sizeof(double) * K * ORC_STATE);
+    orc_gmm_waypoint(cfg, seed, w, state, 0, N, mom, last ? last_samples : NULL,
+                     last ? last_flags : NULL, NULL);
+    if (moments_out) memcpy(moments_out + (size_t)w * K * ORC_NMOM, mom, sizeof(double) * K * ORC_NMOM);
+    double collided = 0.0;
+    for (int k = 0; k < K; ++k) collided += mom[k * ORC_NMOM + 1];
+    double p = collided / (1.0 * (double)N);                             /* :639 */
+    if (probs_out) probs_out[w] = p;
+    prod *= (1.0 - p);                                                   /* :848-851 */
+    if (!last) {
+      orc_gmm_advance(cfg, state, mom, applied + 3 * w, Md + 3 * w, z + (size_t)L * w, next);
+      memcpy(state, next, sizeof state);
+    }
+  }
+  free(applied); free(Md); free(z);
+  return 1.0 - prod;                                                     /* :856 */
+}

@@ -1,0 +1,62 @@
+// pocs_collide.h -- the collision predicate (product code, host + device).
+//
+// Stands in for MCSimulator::checkCollision (MCSimulator.h:257-285), i.e. for
+// robot->SetActiveDOFValues + env->CheckCollision(robot) (:275,:279).  OpenRAVE, its ODE checker
+// and the PR2 model are not part of the reference tree, so this is the build's own explicit 2-D
+// model: one oriented footprint box carried by the base pose (x, y, theta) against M static
+// oriented boxes, separating-axis test on the four face normals.  Touching counts as collision.
+//
+// Obstacle record (POCS_OBS_STRIDE doubles), prepared once on the host by pocs_prepare_obstacle:
+//   cx cy   centre            ax ay   unit x-axis of the box (cos yaw, sin yaw)
+//   hx hy   half extents      bx by   half extents of its world AABB grown by the footprint's
+//                                     bounding radius (broad phase; purely conservative)
+#pragma once
+#include "pocs_math.h"
+
+#define POCS_OBS_STRIDE 8
+#define POCS_MAX_OBSTACLES 64
+
+struct pocs_footprint { double dx, dy, hx, hy; };   // offset in the base frame, half extents
+
+POCS_HD void pocs_prepare_obstacle(const double box5[5], const pocs_footprint* fp, double* rec) {
+  double sn, cs;
+  pocs_sincos(box5[4], &sn, &cs);
+  const double rr = sqrt(fp->hx * fp->hx + fp->hy * fp->hy);
+  rec[0] = box5[0]; rec[1] = box5[1];
+  rec[2] = cs; rec[3] = sn;
+  rec[4] = box5[2]; rec[5] = box5[3];
+  rec[6] = (box5[2] * fabs(cs) + box5[3] * fabs(sn)) + rr;
+  rec[7] = (box5[2] * fabs(sn) + box5[3] * fabs(cs)) + rr;
+}
+
+// Footprint at pose (x, y, theta) with (sn, cs) = sincos(theta) against one obstacle record.
+POCS_HD bool pocs_box_hit(double px, double py, double sn, double cs, double rx, double ry,
+                          const double* o) {
+  const double dx = o[0] - px;
+  const double dy = o[1] - py;
+  if (fabs(dx) > o[6] || fabs(dy) > o[7]) return false;          // broad phase
+  const double ax = o[2], ay = o[3], hx = o[4], hy = o[5];
+  const double acr = fabs(fma(cs, ax, sn * ay));                  // |cos| of the relative yaw
+  const double asr = fabs(fma(sn, ax, -(cs * ay)));               // |sin| of the relative yaw
+  const double d1 = fma(dx, cs, dy * sn);                         // d in the footprint frame
+  const double d2 = fma(dy, cs, -(dx * sn));
+  const double e1 = fma(dx, ax, dy * ay);                         // d in the obstacle frame
+  const double e2 = fma(dy, ax, -(dx * ay));
+  const bool sep = (fabs(d1) > rx + fma(hx, acr, hy * asr)) |
+                   (fabs(d2) > ry + fma(hx, asr, hy * acr)) |
+                   (fabs(e1) > hx + fma(rx, acr, ry * asr)) |
+                   (fabs(e2) > hy + fma(rx, asr, ry * acr));
+  return !sep;
+}
+
+// checkCollision for one pose: true if the footprint touches any of the M obstacles.
+POCS_HD bool pocs_pose_collides(double x, double y, double th, const pocs_footprint* fp,
+                                const double* obs, int M) {
+  double sn, cs;
+  pocs_sincos(th, &sn, &cs);
+  const double px = x + fma(cs, fp->dx, -(sn * fp->dy));
+  const double py = y + fma(sn, fp->dx, cs * fp->dy);
+  bool hit = false;
+  for (int m = 0; m < M; ++m) hit = hit | pocs_box_hit(px, py, sn, cs, fp->hx, fp->hy, obs + m * POCS_OBS_STRIDE);
+  return hit;
+}

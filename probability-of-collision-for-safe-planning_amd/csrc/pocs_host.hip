@@ -1,0 +1,1069 @@
+// pocs_host.hip -- host runtime behind the C ABI (include/pocs.h): configuration state, the
+// per-waypoint host chain, device buffers, launch sequences (eager or replayed from a hipGraph)
+// and the MCModule-compatible text dispatcher.
+//
+// Mirrors, on the host side: MCModule (mcsimplugin/mcsimplugin.cpp:7-232) and the O(1) part of
+// MCSimulator::EKF_GaussProp (mcsimplugin/MCSimulator.h:649-864).  Everything per particle /
+// per sample runs in pocs_kernels.hip.  There is no CPU path for that work: without a HIP device
+// pocs_create fails.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pocs.h"
+#include "pocs_kernels.h"
+
+#define POCS_VERSION_STRING "pocs-mi355x 0.1 (gfx950; numerics v1)"
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct pocs_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  std::string err;
+
+  // ---- configuration (what MCSimulator holds, MCSimulator.h:94-136) ----
+  double alphas[4] = {1, 1, 1, 1};      // ones, as the reference ctor leaves them (:143)
+  bool have_alphas = false;
+  pocs_sensor sensor;
+  bool have_q = false, have_landmarks = false;
+  int num_landmarks = -1;
+  long long num_particles = -1;
+  double cov0[9];
+  bool have_cov0 = false;
+  int W = -1;
+  std::vector<double> traj, odom;        // by component: 3 x W, 3 x (W-1)
+  bool have_traj = false, have_odom = false;
+  int K = -1;
+  long long num_gmm = -1;
+  uint64_t seed = 0x5EED0001ull;
+  uint64_t run_index = 0;
+  pocs_footprint fp = {0.0, 0.0, 0.334, 0.334};
+  std::vector<double> boxes;             // M x 5
+  long long shard_first = -1, shard_count = -1;
+  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0;
+  unsigned long long epoch = 0;          // bumped by every setter; part of the graph cache key
+
+  // ---- device state ----
+  DevBuf d_env, d_sensor, d_hdr, d_chain, d_state, d_param, d_moments, d_partial;
+  DevBuf d_sx, d_sy, d_st, d_flags, d_px, d_py, d_pt, d_hits, d_total;
+  double* ext_moments = nullptr;         // caller-owned moments buffer (multi-GPU), or null
+  long long ext_moments_len = 0;
+  void* h_pin = nullptr;                 // pinned staging: hdr | chain | state0 | moments | total
+  size_t h_pin_cap = 0;
+  bool env_dirty = true, sensor_dirty = true;
+
+  hipGraphExec_t graph_gmm = nullptr, graph_mc = nullptr;
+  std::string graph_gmm_key, graph_mc_key;
+
+  std::vector<hipEvent_t> events;
+  double prof_ms = 0.0;
+  long long prof_launches = 0;
+
+  // ---- results of the last run ----
+  std::vector<double> h_chain;           // (W-1) x POCS_CHAIN_STRIDE
+  std::vector<double> h_mu, h_cov;       // (W-1) x 3, (W-1) x 9 : main EKF after each step
+  std::vector<double> probs;             // W
+  std::vector<double> last_moments;      // W x K x 11
+  long long last_gmm_count = 0, last_mc_count = 0;
+  int last_gmm_wp = -1;
+  bool gmm_open = false;
+};
+
+namespace {
+
+int fail(pocs_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail((c), POCS_E_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+int ensure(pocs_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (b.cap >= bytes) return POCS_OK;
+  if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  HIPCHK(c, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return POCS_OK;
+}
+
+void drop_graphs(pocs_ctx* c) {
+  if (c->graph_gmm) { hipGraphExecDestroy(c->graph_gmm); c->graph_gmm = nullptr; }
+  if (c->graph_mc) { hipGraphExecDestroy(c->graph_mc); c->graph_mc = nullptr; }
+  c->graph_gmm_key.clear();
+  c->graph_mc_key.clear();
+}
+
+int grid_for(long long count) {
+  // ~8 evaluations per thread, capped (grid-stride beyond that); >= 1 block
+  long long nb = (count + (long long)POCS_BLOCK * 8 - 1) / ((long long)POCS_BLOCK * 8);
+  if (nb < 1) nb = 1;
+  if (nb > POCS_MAX_BLOCKS) nb = POCS_MAX_BLOCKS;
+  return (int)nb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host chain: everything in EKF_GaussProp's loop body that does not touch particles/samples
+// (MCSimulator.h:692-800): M (generateM_EKF :495-513), gain L and applied control (:714-726,
+// generateL :532-553, inverseOdometry :434-449), EKFpredict on the main estimate (:746),
+// sampleOdometry (:754, :391-410), the L noisy range observations (:786-789, :383-387) and
+// EKFupdate (:797-800).  Noise comes from Philox stream POCS_STREAM_CHAIN, index = step,
+// draw order r1, tr, r2, z_0 .. z_{L-1} as in the reference (:403-405, :786-789).
+// ---------------------------------------------------------------------------------------------
+void inverse_odometry(const double p1[3], const double p2[3], double out[3]) {
+  double r1 = atan2(p2[1] - p1[1], p2[0] - p1[0]) - p1[2];
+  r1 = pocs_wrap_angle(r1);
+  const double ddx = p2[0] - p1[0], ddy = p2[1] - p1[1];
+  const double tr = sqrt(ddx * ddx + ddy * ddy);
+  double r2 = p2[2] - p1[2] - r1;
+  r2 = pocs_wrap_angle(r2);
+  out[0] = r1; out[1] = tr; out[2] = r2;
+}
+
+double chain_normal(uint64_t seed, int step, int draw) {
+  const pocs_u32x4 w = pocs_draw(seed, (uint64_t)step, 0u, POCS_STREAM_CHAIN, (uint32_t)(draw >> 1));
+  double n0, n1;
+  pocs_normal_pair(w.x, w.y, w.z, &n0, &n1);
+  return (draw & 1) ? n1 : n0;
+}
+
+void compute_chain(pocs_ctx* c, uint64_t seed) {
+  const int W = c->W, L = c->sensor.L;
+  c->h_chain.assign((size_t)(W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE, 0.0);
+  c->h_mu.assign((size_t)(W > 1 ? W - 1 : 1) * 3, 0.0);
+  c->h_cov.assign((size_t)(W > 1 ? W - 1 : 1) * 9, 0.0);
+  double mu[3] = {c->traj[0], c->traj[W], c->traj[2 * W]};
+  double cov[9];
+  memcpy(cov, c->cov0, sizeof cov);
+  double real[3] = {mu[0], mu[1], mu[2]};
+  const double a1 = c->alphas[0], a2 = c->alphas[1], a3 = c->alphas[2], a4 = c->alphas[3];
+  for (int i = 0; i < W - 1; ++i) {
+    double* rec = &c->h_chain[(size_t)i * POCS_CHAIN_STRIDE];
+    const double us[3] = {c->odom[i], c->odom[(W - 1) + i], c->odom[2 * (W - 1) + i]};
+    const double xs[3] = {c->traj[i], c->traj[W + i], c->traj[2 * W + i]};
+    const double xg[3] = {c->traj[i + 1], c->traj[W + i + 1], c->traj[2 * W + i + 1]};
+    // generateM_EKF on the NOMINAL control
+    rec[3] = a1 * (us[0] * us[0]) + a2 * (us[1] * us[1]);
+    rec[4] = a3 * (us[1] * us[1]) + a4 * (us[0] * us[0]) + a4 * (us[2] * us[2]);
+    rec[5] = a1 * (us[2] * us[2]) + a2 * (us[1] * us[1]);
+    // generateL + applied control
+    double ureq[3], applied[3];
+    inverse_odometry(mu, xg, ureq);
+    for (int j = 0; j < 3; ++j) {
+      const double xhat = mu[j] - xs[j];
+      const double ubar = ureq[j] - us[j];
+      const double gain = ubar / (xhat != 0 ? xhat : 0.1);
+      applied[j] = us[j] + gain * xhat;
+      rec[j] = applied[j];
+    }
+    // EKFpredict on the main estimate
+    double pmu[3], pcov[9];
+    pocs_ekf_predict(mu, cov, applied, rec + 3, pmu, pcov);
+    // sampleOdometry on the APPLIED control
+    const double v0 = a1 * (applied[0] * applied[0]) + a2 * (applied[1] * applied[1]);
+    const double v1 = a3 * (applied[1] * applied[1]) +
+                      a4 * ((applied[0] * applied[0]) + (applied[2] * applied[2]));
+    const double v2 = a1 * (applied[2] * applied[2]) + a2 * (applied[1] * applied[1]);
+    double noisy[3];
+    noisy[0] = applied[0] + chain_normal(seed, i, 0) * sqrt(v0);
+    noisy[1] = applied[1] + chain_normal(seed, i, 1) * sqrt(v1);
+    noisy[2] = applied[2] + chain_normal(seed, i, 2) * sqrt(v2);
+    rec[6] = noisy[0]; rec[7] = noisy[1]; rec[8] = noisy[2];
+    double next[3];
+    pocs_motion(real, noisy, next);
+    real[0] = next[0]; real[1] = next[1]; real[2] = next[2];
+    // noisy range observations of the real state
+    for (int l = 0; l < L; ++l) {
+      const double dx = real[0] - c->sensor.lx[l], dy = real[1] - c->sensor.ly[l];
+      const double dist = sqrt(dx * dx + dy * dy);
+      rec[POCS_CHAIN_Z + l] = dist + (0.0 + chain_normal(seed, i, 3 + l) * sqrt(c->sensor.Q));
+    }
+    pocs_ekf_update(pmu, pcov, rec + POCS_CHAIN_Z, &c->sensor);
+    memcpy(mu, pmu, sizeof mu);
+    memcpy(cov, pcov, sizeof cov);
+    memcpy(&c->h_mu[(size_t)i * 3], mu, sizeof mu);
+    memcpy(&c->h_cov[(size_t)i * 9], cov, sizeof cov);
+  }
+}
+
+int check_common(pocs_ctx* c) {
+  if (!c->have_q || !c->have_landmarks) return fail(c, POCS_E_STATE, "setQ / setLandmarks missing");
+  if (!c->have_cov0) return fail(c, POCS_E_STATE, "setInitialCovariance missing");
+  if (!c->have_traj || !c->have_odom) return fail(c, POCS_E_STATE, "setTrajectory / setOdometry missing");
+  if (c->W < 1) return fail(c, POCS_E_STATE, "setPathLength missing");
+  return POCS_OK;
+}
+
+int upload_static(pocs_ctx* c) {
+  if (c->env_dirty) {
+    pocs_env_dev env;
+    memset(&env, 0, sizeof env);
+    env.fp = c->fp;
+    env.M = (int)(c->boxes.size() / 5);
+    for (int m = 0; m < env.M; ++m)
+      pocs_prepare_obstacle(&c->boxes[(size_t)m * 5], &c->fp, &env.obs[(size_t)m * POCS_OBS_STRIDE]);
+    if (int r = ensure(c, c->d_env, sizeof env)) return r;
+    HIPCHK(c, hipMemcpy(c->d_env.p, &env, sizeof env, hipMemcpyHostToDevice));
+    c->env_dirty = false;
+  }
+  if (c->sensor_dirty) {
+    if (int r = ensure(c, c->d_sensor, sizeof(pocs_sensor))) return r;
+    HIPCHK(c, hipMemcpy(c->d_sensor.p, &c->sensor, sizeof(pocs_sensor), hipMemcpyHostToDevice));
+    c->sensor_dirty = false;
+  }
+  return POCS_OK;
+}
+
+// pinned staging layout (doubles): [0..1] header, then chain, then state0, then moments, total
+struct PinLayout { size_t chain, state0, moments, total, end; };
+PinLayout pin_layout(const pocs_ctx* c) {
+  PinLayout p;
+  const size_t W = (size_t)(c->W > 0 ? c->W : 1), K = (size_t)(c->K > 0 ? c->K : 1);
+  p.chain = 2;
+  p.state0 = p.chain + (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE;
+  p.moments = p.state0 + K * POCS_STATE_STRIDE;
+  p.total = p.moments + W * K * POCS_NMOM;
+  p.end = p.total + 2;
+  return p;
+}
+
+int ensure_pin(pocs_ctx* c) {
+  const size_t bytes = pin_layout(c).end * sizeof(double);
+  if (c->h_pin_cap >= bytes) return POCS_OK;
+  if (c->h_pin) { HIPCHK(c, hipHostFree(c->h_pin)); c->h_pin = nullptr; c->h_pin_cap = 0; }
+  HIPCHK(c, hipHostMalloc(&c->h_pin, bytes, hipHostMallocDefault));
+  c->h_pin_cap = bytes;
+  drop_graphs(c);   // captured copies hold the old staging pointers
+  return POCS_OK;
+}
+
+uint64_t effective_seed(const pocs_ctx* c) {
+  // every run of a context draws a fresh stream (the reference re-draws on each run*,
+  // MCSimulator.h:656-679); setSeed rewinds run_index so (seed, run) is reproducible.
+  return c->seed + 0x9E3779B97F4A7C15ull * c->run_index;
+}
+
+double* moments_dev(pocs_ctx* c) { return c->ext_moments ? c->ext_moments : (double*)c->d_moments.p; }
+
+int prof_begin(pocs_ctx* c, size_t launches) {
+  c->prof_ms = 0.0; c->prof_launches = 0;
+  if (!c->opt_profile) return POCS_OK;
+  while (c->events.size() < 2 * launches) {
+    hipEvent_t e;
+    HIPCHK(c, hipEventCreate(&e));
+    c->events.push_back(e);
+  }
+  return POCS_OK;
+}
+int prof_collect(pocs_ctx* c, size_t launches) {
+  if (!c->opt_profile) return POCS_OK;
+  for (size_t i = 0; i < launches; ++i) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->events[2 * i], c->events[2 * i + 1]));
+    c->prof_ms += ms;
+  }
+  c->prof_launches = (long long)launches;
+  return POCS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// GMM path
+// ------------------------------------------------------------------------------------------
+int gmm_shard(pocs_ctx* c, long long* first, long long* count) {
+  *first = c->shard_first >= 0 ? c->shard_first : 0;
+  *count = c->shard_first >= 0 ? c->shard_count : c->num_gmm;
+  if (*first < 0 || *count < 0 || *first + *count > c->num_gmm)
+    return fail(c, POCS_E_ARG, "shard [%lld,+%lld) outside numGMMSamples=%lld", *first, *count, c->num_gmm);
+  return POCS_OK;
+}
+
+int gmm_prepare(pocs_ctx* c) {
+  if (int r = check_common(c)) return r;
+  if (c->K < 1) return fail(c, POCS_E_STATE, "setNumGaussians missing");
+  if (c->num_gmm < 1) return fail(c, POCS_E_STATE, "setNumGMMSamples missing");
+  long long first, count;
+  if (int r = gmm_shard(c, &first, &count)) return r;
+  if (int r = upload_static(c)) return r;
+  const size_t W = (size_t)c->W, K = (size_t)c->K;
+  const int nblk = grid_for(count);
+  if (int r = ensure(c, c->d_hdr, sizeof(pocs_run_header))) return r;
+  if (int r = ensure(c, c->d_chain, (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_state, W * K * POCS_STATE_STRIDE * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_param, W * K * POCS_PARAM_STRIDE * sizeof(double))) return r;
+  if (!c->ext_moments)
+    if (int r = ensure(c, c->d_moments, W * K * POCS_NMOM * sizeof(double))) return r;
+  if (c->ext_moments && c->ext_moments_len < (long long)(W * K * POCS_NMOM))
+    return fail(c, POCS_E_BUFFER, "bound moments buffer too small");
+  if (int r = ensure(c, c->d_partial, (size_t)nblk * K * POCS_NMOM * sizeof(double))) return r;
+  if (c->opt_store) {
+    const size_t n = (size_t)(count > 0 ? count : 1);
+    if (int r = ensure(c, c->d_sx, n * sizeof(double))) return r;
+    if (int r = ensure(c, c->d_sy, n * sizeof(double))) return r;
+    if (int r = ensure(c, c->d_st, n * sizeof(double))) return r;
+    if (int r = ensure(c, c->d_flags, n * sizeof(int16_t))) return r;
+  }
+  return ensure_pin(c);
+}
+
+// host staging -> device: run header, chain, initial mixture (initGMM, MCSimulator.h:350-352,
+// GM_Model.h:57-77: K copies of (mu0, Sigma0), weights 1/K)
+int gmm_upload_run(pocs_ctx* c, uint64_t seed) {
+  compute_chain(c, seed);
+  const PinLayout pl = pin_layout(c);
+  double* pin = (double*)c->h_pin;
+  pocs_run_header hdr; hdr.seed = seed; hdr.pad = 0;
+  memcpy(pin, &hdr, sizeof hdr);
+  memcpy(pin + pl.chain, c->h_chain.data(), c->h_chain.size() * sizeof(double));
+  const int W = c->W;
+  for (int k = 0; k < c->K; ++k) {
+    double* s = pin + pl.state0 + (size_t)k * POCS_STATE_STRIDE;
+    s[0] = c->traj[0]; s[1] = c->traj[W]; s[2] = c->traj[2 * W];
+    memcpy(s + 3, c->cov0, 9 * sizeof(double));
+    s[12] = 1.0 / c->K; s[13] = 1.0; s[14] = 0.0; s[15] = 0.0;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, pin, sizeof hdr, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_chain.p, pin + pl.chain, c->h_chain.size() * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_state.p, pin + pl.state0, (size_t)c->K * POCS_STATE_STRIDE * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+  return POCS_OK;
+}
+
+int enqueue_finalize(pocs_ctx* c, int nblk, int reduce_wp, int advance_wp) {
+  pocs_finalize_launch f;
+  f.partial = (const double*)c->d_partial.p; f.nblk = nblk;
+  f.moments = moments_dev(c);
+  f.state = (double*)c->d_state.p; f.param = (double*)c->d_param.p;
+  f.chain = (const double*)c->d_chain.p; f.sensor = (const pocs_sensor*)c->d_sensor.p;
+  f.K = c->K; f.reduce_wp = reduce_wp; f.advance_wp = advance_wp;
+  HIPCHK(c, pocs_launch_gmm_finalize(f, c->stream));
+  return POCS_OK;
+}
+
+int enqueue_sample(pocs_ctx* c, int nblk, long long first, long long count, int w, int prof_slot) {
+  pocs_gmm_launch a;
+  a.hdr = (const pocs_run_header*)c->d_hdr.p;
+  a.env = (const pocs_env_dev*)c->d_env.p;
+  a.param = (const double*)c->d_param.p + (size_t)w * c->K * POCS_PARAM_STRIDE;
+  a.x = (double*)c->d_sx.p; a.y = (double*)c->d_sy.p; a.th = (double*)c->d_st.p;
+  a.flags = (int16_t*)c->d_flags.p;
+  a.partial = (double*)c->d_partial.p;
+  a.first = first; a.count = count; a.waypoint = w; a.store = c->opt_store ? 1 : 0;
+  if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot], c->stream));
+  HIPCHK(c, pocs_launch_gmm_sample(c->K, nblk, a, c->stream));
+  if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot + 1], c->stream));
+  return POCS_OK;
+}
+
+int enqueue_gmm_all(pocs_ctx* c, long long first, long long count, bool prof) {
+  const int W = c->W, nblk = grid_for(count);
+  for (int w = 0; w < W; ++w) {
+    if (int r = enqueue_finalize(c, nblk, w - 1, w)) return r;
+    if (int r = enqueue_sample(c, nblk, first, count, w, prof ? w : -1)) return r;
+  }
+  if (int r = enqueue_finalize(c, nblk, W - 1, -1)) return r;
+  const PinLayout pl = pin_layout(c);
+  HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.moments, moments_dev(c),
+                           (size_t)W * c->K * POCS_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  return POCS_OK;
+}
+
+// F1 (MCSimulator.h:848-856): p_w = colliding / numGMMSamples (:633-641), result = 1 - prod(1 - p_w)
+void gmm_combine(pocs_ctx* c, const double* moments, double* probability) {
+  const int W = c->W, K = c->K;
+  c->probs.assign(W, 0.0);
+  c->last_moments.assign(moments, moments + (size_t)W * K * POCS_NMOM);
+  double prod = 1.0;
+  for (int w = 0; w < W; ++w) {
+    double coll = 0.0;
+    for (int k = 0; k < K; ++k) coll += moments[((size_t)w * K + k) * POCS_NMOM + 1];
+    const double p = coll / (1.0 * (double)c->num_gmm);
+    c->probs[w] = p;
+    prod *= (1.0 - p);
+  }
+  *probability = 1.0 - prod;
+}
+
+std::string config_key(const pocs_ctx* c, long long first, long long count, const char* tag) {
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s e%llu W%d K%d n%lld f%lld c%lld s%lld fu%lld st%p em%p", tag, c->epoch,
+           c->W, c->K, c->num_gmm, first, count, c->opt_store, c->opt_fused, (void*)c->stream,
+           (void*)c->ext_moments);
+  return buf;
+}
+
+int run_gmm_full(pocs_ctx* c, double* probability) {
+  if (!probability) return fail(c, POCS_E_ARG, "null output");
+  if (int r = gmm_prepare(c)) return r;
+  long long first, count;
+  if (int r = gmm_shard(c, &first, &count)) return r;
+  const uint64_t seed = effective_seed(c);
+  c->run_index++;
+  if (int r = gmm_upload_run(c, seed)) return r;
+  const bool prof = c->opt_profile != 0;
+  if (int r = prof_begin(c, (size_t)c->W)) return r;
+  if (c->opt_graph && !prof) {
+    const std::string key = config_key(c, first, count, "gmm");
+    if (!c->graph_gmm || key != c->graph_gmm_key) {
+      if (c->graph_gmm) { hipGraphExecDestroy(c->graph_gmm); c->graph_gmm = nullptr; }
+      hipGraph_t g = nullptr;
+      HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      int r = enqueue_gmm_all(c, first, count, false);
+      hipError_t e = hipStreamEndCapture(c->stream, &g);
+      if (r) { if (g) hipGraphDestroy(g); return r; }
+      HIPCHK(c, e);
+      e = hipGraphInstantiate(&c->graph_gmm, g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      HIPCHK(c, e);
+      c->graph_gmm_key = key;
+    }
+    HIPCHK(c, hipGraphLaunch(c->graph_gmm, c->stream));
+  } else {
+    if (int r = enqueue_gmm_all(c, first, count, prof)) return r;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int r = prof_collect(c, (size_t)c->W)) return r;
+  gmm_combine(c, (double*)c->h_pin + pin_layout(c).moments, probability);
+  c->last_gmm_count = count;
+  c->last_gmm_wp = c->W - 1;
+  return POCS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// MC path
+// ------------------------------------------------------------------------------------------
+int mc_shard(pocs_ctx* c, long long* first, long long* count) {
+  *first = c->shard_first >= 0 ? c->shard_first : 0;
+  *count = c->shard_first >= 0 ? c->shard_count : c->num_particles;
+  if (*first < 0 || *count < 0 || *first + *count > c->num_particles)
+    return fail(c, POCS_E_ARG, "shard [%lld,+%lld) outside numParticles=%lld", *first, *count, c->num_particles);
+  return POCS_OK;
+}
+
+int enqueue_mc_all(pocs_ctx* c, long long first, long long count, bool prof) {
+  const int W = c->W, nblk = grid_for(count);
+  pocs_mc_launch a;
+  a.hdr = (const pocs_run_header*)c->d_hdr.p;
+  a.env = (const pocs_env_dev*)c->d_env.p;
+  a.chain = (const double*)c->d_chain.p;
+  a.x = (double*)c->d_px.p; a.y = (double*)c->d_py.p; a.th = (double*)c->d_pt.p;
+  a.hits = (uint32_t*)c->d_hits.p;
+  a.first = first; a.count = count;
+  a.mu0[0] = c->traj[0]; a.mu0[1] = c->traj[W]; a.mu0[2] = c->traj[2 * W];
+  if (!pocs_chol3_lower(c->cov0, a.L0)) return fail(c, POCS_E_ARG, "initial covariance is not positive definite");
+  HIPCHK(c, hipMemsetAsync(c->d_total.p, 0, 16, c->stream));
+  if (c->opt_fused) {
+    a.step = W - 1;
+    if (prof) HIPCHK(c, hipEventRecord(c->events[0], c->stream));
+    HIPCHK(c, pocs_launch_mc_fused(nblk, a, c->stream));
+    if (prof) HIPCHK(c, hipEventRecord(c->events[1], c->stream));
+  } else {
+    a.step = 0;
+    HIPCHK(c, pocs_launch_mc_init(nblk, a, c->stream));
+    for (int s = 0; s < W - 1; ++s) {
+      a.step = s;
+      if (prof) HIPCHK(c, hipEventRecord(c->events[2 * s], c->stream));
+      HIPCHK(c, pocs_launch_mc_step(nblk, a, c->stream));
+      if (prof) HIPCHK(c, hipEventRecord(c->events[2 * s + 1], c->stream));
+    }
+  }
+  HIPCHK(c, pocs_launch_mc_count(nblk, (const uint32_t*)c->d_hits.p, count,
+                                 (unsigned long long*)c->d_total.p, c->stream));
+  const PinLayout pl = pin_layout(c);
+  HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.total, c->d_total.p, sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, c->stream));
+  return POCS_OK;
+}
+
+int run_mc_local(pocs_ctx* c, unsigned long long* collided) {
+  if (!collided) return fail(c, POCS_E_ARG, "null output");
+  if (int r = check_common(c)) return r;
+  if (c->num_particles < 1) return fail(c, POCS_E_STATE, "setNumParticles missing");
+  long long first, count;
+  if (int r = mc_shard(c, &first, &count)) return r;
+  if (int r = upload_static(c)) return r;
+  const size_t W = (size_t)c->W, n = (size_t)(count > 0 ? count : 1);
+  if (int r = ensure(c, c->d_hdr, sizeof(pocs_run_header))) return r;
+  if (int r = ensure(c, c->d_chain, (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_px, n * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_py, n * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_pt, n * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_hits, n * sizeof(uint32_t))) return r;
+  if (int r = ensure(c, c->d_total, 16)) return r;
+  if (int r = ensure_pin(c)) return r;
+  const uint64_t seed = effective_seed(c);
+  c->run_index++;
+  compute_chain(c, seed);
+  const PinLayout pl = pin_layout(c);
+  double* pin = (double*)c->h_pin;
+  pocs_run_header hdr; hdr.seed = seed; hdr.pad = 0;
+  memcpy(pin, &hdr, sizeof hdr);
+  memcpy(pin + pl.chain, c->h_chain.data(), c->h_chain.size() * sizeof(double));
+  HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, pin, sizeof hdr, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_chain.p, pin + pl.chain, c->h_chain.size() * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+  const bool prof = c->opt_profile != 0;
+  const size_t nprof = c->opt_fused ? 1 : (W > 1 ? W - 1 : 0);
+  if (int r = prof_begin(c, nprof > 0 ? nprof : 1)) return r;
+  if (c->opt_graph && !prof) {
+    const std::string key = config_key(c, first, count, "mc") + std::to_string(c->num_particles);
+    if (!c->graph_mc || key != c->graph_mc_key) {
+      if (c->graph_mc) { hipGraphExecDestroy(c->graph_mc); c->graph_mc = nullptr; }
+      hipGraph_t g = nullptr;
+      HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      int r = enqueue_mc_all(c, first, count, false);
+      hipError_t e = hipStreamEndCapture(c->stream, &g);
+      if (r) { if (g) hipGraphDestroy(g); return r; }
+      HIPCHK(c, e);
+      e = hipGraphInstantiate(&c->graph_mc, g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      HIPCHK(c, e);
+      c->graph_mc_key = key;
+    }
+    HIPCHK(c, hipGraphLaunch(c->graph_mc, c->stream));
+  } else {
+    if (int r = enqueue_mc_all(c, first, count, prof)) return r;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int r = prof_collect(c, nprof)) return r;
+  unsigned long long tot;
+  memcpy(&tot, pin + pl.total, sizeof tot);
+  *collided = tot;
+  c->last_mc_count = count;
+  return POCS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// text dispatcher
+// ------------------------------------------------------------------------------------------
+bool split_numbers(const char* s, std::vector<double>* out) {
+  out->clear();
+  while (*s) {
+    while (*s == ' ' || *s == '\t' || *s == '\n' || *s == '\r') ++s;
+    if (!*s) break;
+    char* end = nullptr;
+    const double v = strtod(s, &end);
+    if (end == s) return false;
+    if (*end && *end != ' ' && *end != '\t' && *end != '\n' && *end != '\r') return false;
+    out->push_back(v);
+    s = end;
+  }
+  return true;
+}
+
+int put(pocs_ctx* c, char* out, size_t cap, const char* text) {
+  if (!out || cap == 0) return POCS_OK;
+  const size_t n = strlen(text);
+  if (n + 1 > cap) { out[0] = 0; return fail(c, POCS_E_BUFFER, "reply needs %zu bytes", n + 1); }
+  memcpy(out, text, n + 1);
+  return POCS_OK;
+}
+
+bool is_integer(double v) { return v == floor(v) && fabs(v) < 9.0e15; }
+
+const char* kHelp =
+    "MyCommand        This is an example command\n"
+    "ArmaCommand      kept for compatibility (no-op)\n"
+    "setAlphas        a1 a2 a3 a4: squared odometry noise coefficients\n"
+    "setQ             q: variance of the range sensor noise\n"
+    "setNumLandmarks  n\n"
+    "setLandmarks     x_0..x_{n-1} y_0..y_{n-1}\n"
+    "setNumParticles  n: particles of the MC simulation\n"
+    "setInitialCovariance  c00 c01 c02 c10 .. c22 (row major)\n"
+    "setPathLength    W\n"
+    "setTrajectory    x_0..x_{W-1} y_0..y_{W-1} theta_0..theta_{W-1}\n"
+    "setOdometry      r1_0.. tr_0.. r2_0.. (W-1 each)\n"
+    "runSimulation    run the MC simulation, replies the collision probability\n"
+    "setNumGaussians  k: components of the mixture (1..8)\n"
+    "runGMMEstimation sampling-based GMM estimate, replies the collision probability\n"
+    "setNumGMMSamples n: samples per waypoint for the GMM estimate\n"
+    "setSeed          s: 64-bit seed of the counter-based random streams (new)\n"
+    "setFootprint     dx dy half_x half_y (new)\n"
+    "addObstacle      cx cy half_x half_y yaw_rad (new)\n"
+    "clearObstacles   (new)\n"
+    "help             this text\n";
+
+}  // namespace
+
+// ==============================================================================================
+// C ABI
+// ==============================================================================================
+extern "C" {
+
+const char* pocs_version(void) { return POCS_VERSION_STRING; }
+
+int pocs_create(pocs_ctx** out, int device) {
+  if (!out) return POCS_E_ARG;
+  *out = nullptr;
+  pocs_ctx* c = new (std::nothrow) pocs_ctx();
+  if (!c) return POCS_E_ARG;
+  *out = c;        // returned even on failure so the caller can read pocs_last_error
+  memset(&c->sensor, 0, sizeof c->sensor);
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(c, POCS_E_DEVICE, "no HIP device available (%s); libpocs has no CPU path",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device < 0 || device >= n) return fail(c, POCS_E_ARG, "device %d out of range (0..%d)", device, n - 1);
+  c->device = device;
+  HIPCHK(c, hipSetDevice(device));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  return POCS_OK;
+}
+
+void pocs_destroy(pocs_ctx* c) {
+  if (!c) return;
+  if (c->own_stream) {
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    drop_graphs(c);
+    for (hipEvent_t e : c->events) hipEventDestroy(e);
+    DevBuf* all[] = {&c->d_env, &c->d_sensor, &c->d_hdr, &c->d_chain, &c->d_state, &c->d_param,
+                     &c->d_moments, &c->d_partial, &c->d_sx, &c->d_sy, &c->d_st, &c->d_flags,
+                     &c->d_px, &c->d_py, &c->d_pt, &c->d_hits, &c->d_total};
+    for (DevBuf* b : all) if (b->p) hipFree(b->p);
+    if (c->h_pin) hipHostFree(c->h_pin);
+    hipStreamDestroy(c->own_stream);
+  }
+  delete c;
+}
+
+const char* pocs_last_error(const pocs_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int pocs_set_footprint(pocs_ctx* c, double dx, double dy, double hx, double hy) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (!(hx > 0) || !(hy > 0)) return fail(c, POCS_E_ARG, "footprint half extents must be > 0");
+  c->fp.dx = dx; c->fp.dy = dy; c->fp.hx = hx; c->fp.hy = hy;
+  c->env_dirty = true;
+  return POCS_OK;
+}
+
+int pocs_set_obstacles(pocs_ctx* c, const double* boxes, int M) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (M < 0 || M > POCS_MAX_OBSTACLES || (M > 0 && !boxes))
+    return fail(c, POCS_E_ARG, "obstacle count %d outside 0..%d", M, POCS_MAX_OBSTACLES);
+  for (int m = 0; m < M; ++m)
+    if (!(boxes[5 * m + 2] > 0) || !(boxes[5 * m + 3] > 0))
+      return fail(c, POCS_E_ARG, "obstacle %d: half extents must be > 0", m);
+  c->boxes.assign(boxes, boxes + (size_t)M * 5);
+  c->env_dirty = true;
+  return POCS_OK;
+}
+
+int pocs_set_alphas(pocs_ctx* c, const double* a, int n) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (n < 1 || n > 4 || !a) return fail(c, POCS_E_ARG, "setAlphas takes 1..4 values (got %d)", n);
+  for (int i = 0; i < n; ++i) c->alphas[i] = a[i];
+  c->have_alphas = true;
+  return POCS_OK;
+}
+
+int pocs_set_q(pocs_ctx* c, double q) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (!(q >= 0)) return fail(c, POCS_E_ARG, "Q must be >= 0");
+  c->sensor.Q = q; c->have_q = true; c->sensor_dirty = true;
+  return POCS_OK;
+}
+
+int pocs_set_num_landmarks(pocs_ctx* c, int n) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (n < 0 || n > POCS_MAX_LANDMARKS) return fail(c, POCS_E_ARG, "numLandmarks %d outside 0..%d", n, POCS_MAX_LANDMARKS);
+  c->num_landmarks = n; c->have_landmarks = false;
+  return POCS_OK;
+}
+
+int pocs_set_landmarks(pocs_ctx* c, const double* xy, int n) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (c->num_landmarks < 0) return fail(c, POCS_E_ORDER, "setLandmarks before setNumLandmarks");
+  if (n != c->num_landmarks || (n > 0 && !xy)) return fail(c, POCS_E_ARG, "setLandmarks needs 2*%d values", c->num_landmarks);
+  c->sensor.L = n;
+  for (int i = 0; i < n; ++i) { c->sensor.lx[i] = xy[i]; c->sensor.ly[i] = xy[n + i]; }
+  c->have_landmarks = true; c->sensor_dirty = true;
+  return POCS_OK;
+}
+
+int pocs_set_num_particles(pocs_ctx* c, long long n) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (n < 1) return fail(c, POCS_E_ARG, "numParticles must be >= 1");
+  c->num_particles = n;
+  return POCS_OK;
+}
+
+int pocs_set_initial_covariance(pocs_ctx* c, const double* m9) {
+  if (c) c->epoch++;
+  if (!c || !m9) return POCS_E_ARG;
+  memcpy(c->cov0, m9, 9 * sizeof(double));
+  c->have_cov0 = true;
+  return POCS_OK;
+}
+
+int pocs_set_path_length(pocs_ctx* c, int W) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (W < 1) return fail(c, POCS_E_ARG, "pathLength must be >= 1");
+  if (W != c->W) { c->have_traj = false; c->have_odom = false; }
+  c->W = W;
+  return POCS_OK;
+}
+
+int pocs_set_trajectory(pocs_ctx* c, const double* v, int W) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (c->W < 1) return fail(c, POCS_E_ORDER, "setTrajectory before setPathLength");
+  if (W != c->W || !v) return fail(c, POCS_E_ARG, "setTrajectory needs 3*%d values", c->W);
+  c->traj.assign(v, v + (size_t)3 * W);
+  c->have_traj = true;
+  return POCS_OK;
+}
+
+int pocs_set_odometry(pocs_ctx* c, const double* v, int Wm1) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (c->W < 1) return fail(c, POCS_E_ORDER, "setOdometry before setPathLength");
+  if (Wm1 != c->W - 1 || (Wm1 > 0 && !v)) return fail(c, POCS_E_ARG, "setOdometry needs 3*%d values", c->W - 1);
+  c->odom.assign(v, v + (size_t)3 * Wm1);
+  c->have_odom = true;
+  return POCS_OK;
+}
+
+int pocs_set_num_gaussians(pocs_ctx* c, int K) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (K < 1 || K > POCS_MAX_GAUSSIANS) return fail(c, POCS_E_ARG, "numGaussians %d outside 1..%d", K, POCS_MAX_GAUSSIANS);
+  c->K = K;
+  return POCS_OK;
+}
+
+int pocs_set_num_gmm_samples(pocs_ctx* c, long long n) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (n < 1) return fail(c, POCS_E_ARG, "numGMMSamples must be >= 1");
+  c->num_gmm = n;
+  return POCS_OK;
+}
+
+int pocs_set_seed(pocs_ctx* c, uint64_t seed) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  c->seed = seed; c->run_index = 0;
+  return POCS_OK;
+}
+
+int pocs_set_option(pocs_ctx* c, int option, long long value) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  switch (option) {
+    case POCS_OPT_STORE_SAMPLES: c->opt_store = value ? 1 : 0; break;
+    case POCS_OPT_MC_FUSED: c->opt_fused = value ? 1 : 0; break;
+    case POCS_OPT_USE_GRAPH: c->opt_graph = value ? 1 : 0; break;
+    case POCS_OPT_PROFILE: c->opt_profile = value ? 1 : 0; break;
+    default: return fail(c, POCS_E_ARG, "unknown option %d", option);
+  }
+  return POCS_OK;
+}
+
+int pocs_set_shard(pocs_ctx* c, long long first, long long count) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  if (first < 0 || count < 0) return fail(c, POCS_E_ARG, "negative shard");
+  c->shard_first = first; c->shard_count = count;
+  return POCS_OK;
+}
+
+int pocs_set_stream(pocs_ctx* c, void* s) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  drop_graphs(c);
+  return POCS_OK;
+}
+
+int pocs_gmm_bind_moments(pocs_ctx* c, void* dptr, long long len) {
+  if (c) c->epoch++;
+  if (!c) return POCS_E_ARG;
+  c->ext_moments = (double*)dptr; c->ext_moments_len = dptr ? len : 0;
+  drop_graphs(c);
+  return POCS_OK;
+}
+
+int pocs_run_gmm_estimation(pocs_ctx* c, double* probability) {
+  if (!c) return POCS_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  return run_gmm_full(c, probability);
+}
+
+int pocs_run_simulation(pocs_ctx* c, double* probability) {
+  if (!c) return POCS_E_ARG;
+  if (!probability) return fail(c, POCS_E_ARG, "null output");
+  HIPCHK(c, hipSetDevice(c->device));
+  unsigned long long tot = 0;
+  if (int r = run_mc_local(c, &tot)) return r;
+  // getCollisionProportion, MCSimulator.h:324-330 (of the particles this context evaluated)
+  *probability = (double)tot / (double)(c->last_mc_count > 0 ? c->last_mc_count : 1);
+  return POCS_OK;
+}
+
+int pocs_mc_run_local(pocs_ctx* c, unsigned long long* collided) {
+  if (!c) return POCS_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  return run_mc_local(c, collided);
+}
+
+int pocs_gmm_begin(pocs_ctx* c) {
+  if (!c) return POCS_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int r = gmm_prepare(c)) return r;
+  const uint64_t seed = effective_seed(c);
+  c->run_index++;
+  if (int r = gmm_upload_run(c, seed)) return r;
+  if (int r = prof_begin(c, (size_t)c->W)) return r;
+  c->gmm_open = true;
+  c->last_gmm_wp = -1;
+  return POCS_OK;
+}
+
+int pocs_gmm_step_local(pocs_ctx* c, int w) {
+  if (!c) return POCS_E_ARG;
+  if (!c->gmm_open) return fail(c, POCS_E_ORDER, "pocs_gmm_step_local before pocs_gmm_begin");
+  if (w != c->last_gmm_wp + 1 || w >= c->W) return fail(c, POCS_E_ORDER, "waypoint %d out of sequence", w);
+  long long first, count;
+  if (int r = gmm_shard(c, &first, &count)) return r;
+  const int nblk = grid_for(count);
+  if (int r = enqueue_finalize(c, nblk, -1, w)) return r;
+  if (int r = enqueue_sample(c, nblk, first, count, w, c->opt_profile ? w : -1)) return r;
+  if (int r = enqueue_finalize(c, nblk, w, -1)) return r;
+  c->last_gmm_wp = w;
+  c->last_gmm_count = count;
+  return POCS_OK;
+}
+
+void* pocs_gmm_moments_ptr(pocs_ctx* c, int w) {
+  if (!c || w < 0 || w >= c->W || c->K < 1) return nullptr;
+  double* m = moments_dev(c);
+  return m ? m + (size_t)w * c->K * POCS_NMOM : nullptr;
+}
+
+int pocs_gmm_moments_len(const pocs_ctx* c) { return (c && c->K > 0) ? c->K * POCS_NMOM : 0; }
+
+int pocs_gmm_end(pocs_ctx* c, double* probability) {
+  if (!c) return POCS_E_ARG;
+  if (!c->gmm_open) return fail(c, POCS_E_ORDER, "pocs_gmm_end before pocs_gmm_begin");
+  if (c->last_gmm_wp != c->W - 1) return fail(c, POCS_E_ORDER, "pocs_gmm_end after %d of %d waypoints", c->last_gmm_wp + 1, c->W);
+  if (!probability) return fail(c, POCS_E_ARG, "null output");
+  const PinLayout pl = pin_layout(c);
+  HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.moments, moments_dev(c),
+                           (size_t)c->W * c->K * POCS_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int r = prof_collect(c, (size_t)c->W)) return r;
+  gmm_combine(c, (double*)c->h_pin + pl.moments, probability);
+  c->gmm_open = false;
+  return POCS_OK;
+}
+
+int pocs_get_path_length(const pocs_ctx* c) { return c ? c->W : POCS_E_ARG; }
+
+int pocs_get_waypoint_probabilities(pocs_ctx* c, double* out, int cap) {
+  if (!c || !out) return POCS_E_ARG;
+  if ((int)c->probs.size() > cap) return fail(c, POCS_E_BUFFER, "need %zu doubles", c->probs.size());
+  memcpy(out, c->probs.data(), c->probs.size() * sizeof(double));
+  return (int)c->probs.size();
+}
+
+int pocs_get_moments(pocs_ctx* c, int w, double* out, int cap) {
+  if (!c || !out) return POCS_E_ARG;
+  const int n = c->K * POCS_NMOM;
+  if (w < 0 || (size_t)(w + 1) * n > c->last_moments.size()) return fail(c, POCS_E_ARG, "no moments for waypoint %d", w);
+  if (cap < n) return fail(c, POCS_E_BUFFER, "need %d doubles", n);
+  memcpy(out, &c->last_moments[(size_t)w * n], (size_t)n * sizeof(double));
+  return n;
+}
+
+int pocs_get_gmm_state(pocs_ctx* c, int w, double* means3, double* covs9, double* weights) {
+  if (!c) return POCS_E_ARG;
+  if (w < 0 || w > c->last_gmm_wp || !c->d_state.p) return fail(c, POCS_E_ARG, "no mixture for waypoint %d", w);
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<double> s((size_t)c->K * POCS_STATE_STRIDE);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(s.data(), (double*)c->d_state.p + (size_t)w * s.size(), s.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int k = 0; k < c->K; ++k) {
+    if (means3) memcpy(means3 + 3 * k, &s[(size_t)k * POCS_STATE_STRIDE], 3 * sizeof(double));
+    if (covs9) memcpy(covs9 + 9 * k, &s[(size_t)k * POCS_STATE_STRIDE + 3], 9 * sizeof(double));
+    if (weights) weights[k] = s[(size_t)k * POCS_STATE_STRIDE + 12];
+  }
+  return c->K;
+}
+
+int pocs_get_host_chain(pocs_ctx* c, double* applied3, double* noisy3, double* z, double* mu3, double* cov9) {
+  if (!c) return POCS_E_ARG;
+  const int steps = c->W - 1, L = c->sensor.L;
+  if (steps < 0 || c->h_chain.size() < (size_t)(steps > 0 ? steps : 1) * POCS_CHAIN_STRIDE)
+    return fail(c, POCS_E_STATE, "no run yet");
+  for (int i = 0; i < steps; ++i) {
+    const double* rec = &c->h_chain[(size_t)i * POCS_CHAIN_STRIDE];
+    if (applied3) memcpy(applied3 + 3 * i, rec, 3 * sizeof(double));
+    if (noisy3) memcpy(noisy3 + 3 * i, rec + 6, 3 * sizeof(double));
+    if (z) memcpy(z + (size_t)L * i, rec + POCS_CHAIN_Z, (size_t)L * sizeof(double));
+    if (mu3) memcpy(mu3 + 3 * i, &c->h_mu[(size_t)3 * i], 3 * sizeof(double));
+    if (cov9) memcpy(cov9 + 9 * i, &c->h_cov[(size_t)9 * i], 9 * sizeof(double));
+  }
+  return steps;
+}
+
+static long long copy_soa_as_aos(pocs_ctx* c, const DevBuf& bx, const DevBuf& by, const DevBuf& bt,
+                                 long long n, double* aos) {
+  std::vector<double> tmp((size_t)n);
+  const DevBuf* src[3] = {&bx, &by, &bt};
+  for (int j = 0; j < 3; ++j) {
+    if (hipMemcpy(tmp.data(), src[j]->p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (long long i = 0; i < n; ++i) aos[3 * i + j] = tmp[(size_t)i];
+  }
+  (void)c;
+  return n;
+}
+
+long long pocs_copy_gmm_samples(pocs_ctx* c, double* aos, int16_t* flags, long long cap) {
+  if (!c) return POCS_E_ARG;
+  const long long n = c->last_gmm_count;
+  if (!c->opt_store || !c->d_sx.p || c->last_gmm_wp < 0) return fail(c, POCS_E_STATE, "no stored samples");
+  if (cap < n) return fail(c, POCS_E_BUFFER, "need room for %lld samples", n);
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+    return fail(c, POCS_E_DEVICE, "sync failed");
+  if (aos && copy_soa_as_aos(c, c->d_sx, c->d_sy, c->d_st, n, aos) < 0) return fail(c, POCS_E_DEVICE, "copy failed");
+  if (flags && hipMemcpy(flags, c->d_flags.p, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(c, POCS_E_DEVICE, "copy failed");
+  return n;
+}
+
+long long pocs_copy_particles(pocs_ctx* c, double* aos, uint32_t* hits, long long cap) {
+  if (!c) return POCS_E_ARG;
+  const long long n = c->last_mc_count;
+  if (!c->d_px.p || n <= 0) return fail(c, POCS_E_STATE, "no particles");
+  if (cap < n) return fail(c, POCS_E_BUFFER, "need room for %lld particles", n);
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+    return fail(c, POCS_E_DEVICE, "sync failed");
+  if (aos && copy_soa_as_aos(c, c->d_px, c->d_py, c->d_pt, n, aos) < 0) return fail(c, POCS_E_DEVICE, "copy failed");
+  if (hits && hipMemcpy(hits, c->d_hits.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(c, POCS_E_DEVICE, "copy failed");
+  return n;
+}
+
+int pocs_get_kernel_time(pocs_ctx* c, double* total_ms, long long* launches) {
+  if (!c) return POCS_E_ARG;
+  if (total_ms) *total_ms = c->prof_ms;
+  if (launches) *launches = c->prof_launches;
+  return POCS_OK;
+}
+
+int pocs_send_command(pocs_ctx* c, const char* line, char* out, size_t cap) {
+  if (!c || !line) return POCS_E_ARG;
+  if (out && cap) out[0] = 0;
+  while (*line == ' ' || *line == '\t') ++line;
+  const char* sp = line;
+  while (*sp && *sp != ' ' && *sp != '\t' && *sp != '\n') ++sp;
+  const std::string name(line, sp);
+  const char* rest = sp;
+  std::vector<double> v;
+  auto numbers = [&](size_t want) -> int {
+    if (!split_numbers(rest, &v)) return fail(c, POCS_E_ARG, "%s: malformed number", name.c_str());
+    if (v.size() != want) return fail(c, POCS_E_ARG, "%s: expected %zu values, got %zu", name.c_str(), want, v.size());
+    return POCS_OK;
+  };
+  auto one_int = [&](long long* n) -> int {
+    if (int r = numbers(1)) return r;
+    if (!is_integer(v[0])) return fail(c, POCS_E_ARG, "%s: integer expected", name.c_str());
+    *n = (long long)v[0];
+    return POCS_OK;
+  };
+  char buf[64];
+  long long n = 0;
+  if (name == "MyCommand") return put(c, out, cap, "output");                 // mcsimplugin.cpp:225-231
+  if (name == "ArmaCommand") return POCS_OK;                                   // :189-223 (Armadillo demo) -> no-op
+  if (name == "help") return put(c, out, cap, kHelp);
+  if (name == "setAlphas") {                                                   // :174-187
+    if (!split_numbers(rest, &v)) return fail(c, POCS_E_ARG, "setAlphas: malformed number");
+    return pocs_set_alphas(c, v.data(), (int)v.size());
+  }
+  if (name == "setQ") { if (int r = numbers(1)) return r; return pocs_set_q(c, v[0]); }
+  if (name == "setNumLandmarks") { if (int r = one_int(&n)) return r; return pocs_set_num_landmarks(c, (int)n); }
+  if (name == "setLandmarks") {
+    if (c->num_landmarks < 0) return fail(c, POCS_E_ORDER, "setLandmarks before setNumLandmarks");
+    if (int r = numbers((size_t)2 * c->num_landmarks)) return r;
+    return pocs_set_landmarks(c, v.data(), c->num_landmarks);
+  }
+  if (name == "setNumParticles") { if (int r = one_int(&n)) return r; return pocs_set_num_particles(c, n); }
+  if (name == "setInitialCovariance") { if (int r = numbers(9)) return r; return pocs_set_initial_covariance(c, v.data()); }
+  if (name == "setPathLength") { if (int r = one_int(&n)) return r; return pocs_set_path_length(c, (int)n); }
+  if (name == "setTrajectory") {
+    if (c->W < 1) return fail(c, POCS_E_ORDER, "setTrajectory before setPathLength");
+    if (int r = numbers((size_t)3 * c->W)) return r;
+    return pocs_set_trajectory(c, v.data(), c->W);
+  }
+  if (name == "setOdometry") {
+    if (c->W < 1) return fail(c, POCS_E_ORDER, "setOdometry before setPathLength");
+    if (int r = numbers((size_t)3 * (c->W - 1))) return r;
+    return pocs_set_odometry(c, v.data(), c->W - 1);
+  }
+  if (name == "setNumGaussians") { if (int r = one_int(&n)) return r; return pocs_set_num_gaussians(c, (int)n); }
+  if (name == "setNumGMMSamples") { if (int r = one_int(&n)) return r; return pocs_set_num_gmm_samples(c, n); }
+  if (name == "setSeed") {
+    while (*rest == ' ' || *rest == '\t') ++rest;
+    char* end = nullptr;
+    const unsigned long long s = strtoull(rest, &end, 0);
+    if (end == rest) return fail(c, POCS_E_ARG, "setSeed: integer expected");
+    return pocs_set_seed(c, (uint64_t)s);
+  }
+  if (name == "setFootprint") { if (int r = numbers(4)) return r; return pocs_set_footprint(c, v[0], v[1], v[2], v[3]); }
+  if (name == "addObstacle") {
+    if (int r = numbers(5)) return r;
+    std::vector<double> b = c->boxes;
+    b.insert(b.end(), v.begin(), v.end());
+    return pocs_set_obstacles(c, b.data(), (int)(b.size() / 5));
+  }
+  if (name == "clearObstacles") return pocs_set_obstacles(c, nullptr, 0);
+  if (name == "runSimulation" || name == "runGMMEstimation") {                 // :75-81, :66-72
+    double p = 0.0;
+    const int r = (name == "runSimulation") ? pocs_run_simulation(c, &p) : pocs_run_gmm_estimation(c, &p);
+    if (r) return r;
+    snprintf(buf, sizeof buf, "%.17g", p);
+    return put(c, out, cap, buf);
+  }
+  return fail(c, POCS_E_UNKNOWN_COMMAND, "unknown command '%s'", name.c_str());
+}
+
+}  // extern "C"

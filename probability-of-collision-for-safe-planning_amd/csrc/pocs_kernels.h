@@ -1,0 +1,73 @@
+// pocs_kernels.h -- launch interface between the host runtime (pocs_host.hip) and the gfx950
+// kernels (pocs_kernels.hip).  Internal; the public boundary is include/pocs.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pocs_collide.h"
+#include "pocs_model.h"
+
+#define POCS_BLOCK 256
+#define POCS_MAX_BLOCKS 2048
+// chain record (doubles), one per step i < W-1:
+//   [0..2] applied control   [3..5] diag of M   [6..8] the noisy control actually driven (MC)
+//   [9] unused               [10 .. 10+L) the L range observations of the step
+#define POCS_CHAIN_Z 10
+#define POCS_CHAIN_STRIDE 48
+static_assert(POCS_CHAIN_Z + POCS_MAX_LANDMARKS <= POCS_CHAIN_STRIDE, "chain record too small");
+
+struct pocs_env_dev {            // collision world as the kernels see it (one copy in HBM, staged to LDS)
+  pocs_footprint fp;
+  int M;
+  int pad;
+  double obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
+};
+
+struct pocs_run_header {         // per-run scalars read by every kernel (so a captured graph stays valid)
+  uint64_t seed;
+  uint64_t pad;
+};
+
+struct pocs_gmm_launch {
+  const pocs_run_header* hdr;
+  const pocs_env_dev* env;
+  const double* param;           // K x POCS_PARAM_STRIDE for this waypoint
+  double* x; double* y; double* th;   // SoA sample buffers of this shard (may be null when !store)
+  int16_t* flags;
+  double* partial;               // gridDim.x x (K*POCS_NMOM)
+  long long first;               // global index of the shard's first sample
+  long long count;               // samples in this shard
+  int waypoint;
+  int store;
+};
+
+struct pocs_finalize_launch {
+  const double* partial; int nblk;     // block partials of waypoint `reduce_wp`
+  double* moments;                     // [W][K*POCS_NMOM]
+  double* state;                       // [W][K*POCS_STATE_STRIDE]
+  double* param;                       // [W][K*POCS_PARAM_STRIDE]
+  const double* chain;                 // [W-1][POCS_CHAIN_STRIDE]
+  const pocs_sensor* sensor;
+  int K;
+  int reduce_wp;                       // >= 0: fold partials into moments[reduce_wp]
+  int advance_wp;                      // >= 0: build state/param[advance_wp] from state/moments[advance_wp-1]
+};
+
+struct pocs_mc_launch {
+  const pocs_run_header* hdr;
+  const pocs_env_dev* env;
+  const double* chain;                 // noisy control of step s at chain[s*STRIDE+6..8]
+  double* x; double* y; double* th;    // SoA particle state of this shard
+  uint32_t* hits;                      // particlecollisions
+  long long first, count;
+  double mu0[3];
+  double L0[6];
+  int step;                            // k_mc_step: control index; k_mc_fused: number of steps
+};
+
+hipError_t pocs_launch_gmm_sample(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);
+hipError_t pocs_launch_gmm_finalize(const pocs_finalize_launch& a, hipStream_t s);
+hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s);
+hipError_t pocs_launch_mc_step(int nblk, const pocs_mc_launch& a, hipStream_t s);
+hipError_t pocs_launch_mc_fused(int nblk, const pocs_mc_launch& a, hipStream_t s);
+hipError_t pocs_launch_mc_count(int nblk, const uint32_t* hits, long long count,
+                                unsigned long long* total, hipStream_t s);

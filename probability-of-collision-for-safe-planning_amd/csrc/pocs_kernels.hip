@@ -1,0 +1,313 @@
+// pocs_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the hot path.
+//
+//   k_gmm_sample    S1+C1+T1  GM_Model::sampleNPoints (GM_Model.h:83-116) + checkMatrixCollisions
+//                             (MCSimulator.h:241-253) + the moment sums truncateGMM needs
+//                             (:592-611), fused: a sample is born, tested and folded into its
+//                             component's (n, sum x, sum x x^T) in registers; the pose and flag are
+//                             streamed out once (24 B + 2 B per evaluation) for audit.
+//   k_gmm_finalize  T1 tail   fixed-shape reduction of the block partials, truncated mean/cov,
+//                             weights (:597-629), per-component EKF predict/update (:766-771,
+//                             :804-812) and Cholesky for the next waypoint -- all on device so
+//                             the waypoint loop never returns to the host.
+//   k_mc_init       P2+P3     initParticles (:287-297) + first checkParticleCollisions (:333-347)
+//   k_mc_step       P1+P3     moveParticles (:300-322) + checkParticleCollisions, one waypoint,
+//                             particles streamed through HBM (SoA): 24 B in, 24 B out, u32 RMW.
+//   k_mc_fused      P1+P3     same arithmetic, whole roll-out in registers (the controls do not
+//                             depend on the particles), 0 B per evaluation.
+//   k_mc_count      P3        getCollisionProportion (:324-330): |{hits > 0}|.
+//
+// Bound: these are FP64-VALU / HBM streaming kernels, no contraction => no MFMA.  Mixture
+// parameters and the obstacle table are staged in LDS once per block (all lanes read the same
+// obstacle record => LDS broadcast, no bank conflicts; the per-lane component lookup is a
+// 12-double row per lane).  Reductions are wave64 butterflies followed by one LDS pass and a
+// per-block partial row; partials are combined in a fixed order so results are bitwise
+// reproducible run to run (no float atomics).
+#include "pocs_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Stage the collision world into LDS.  s_obs must hold POCS_MAX_OBSTACLES*POCS_OBS_STRIDE doubles.
+__device__ __forceinline__ void stage_env(const pocs_env_dev* __restrict__ env, double* s_obs,
+                                          pocs_footprint* s_fp, int* s_M) {
+  const int M = env->M;
+  for (int i = threadIdx.x; i < M * POCS_OBS_STRIDE; i += blockDim.x) s_obs[i] = env->obs[i];
+  if (threadIdx.x == 0) { *s_fp = env->fp; *s_M = M; }
+}
+
+template <int K, bool STORE>
+__global__ __launch_bounds__(POCS_BLOCK) void k_gmm_sample(pocs_gmm_launch a) {
+  __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
+  __shared__ double s_par[K * POCS_PARAM_STRIDE];
+  __shared__ double s_red[POCS_BLOCK / 64][K * POCS_NMOM];
+  __shared__ pocs_footprint s_fp;
+  __shared__ int s_M;
+
+  stage_env(a.env, s_obs, &s_fp, &s_M);
+  for (int i = threadIdx.x; i < K * POCS_PARAM_STRIDE; i += POCS_BLOCK) s_par[i] = a.param[i];
+  __syncthreads();
+
+  const uint64_t seed = a.hdr->seed;
+  const pocs_footprint fp = s_fp;
+  const int M = s_M;
+
+  double acc[K][9];
+  unsigned nfree[K], ncoll[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    nfree[k] = 0u; ncoll[k] = 0u;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[k][j] = 0.0;
+  }
+
+  const long long stride = (long long)gridDim.x * POCS_BLOCK;
+  for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < a.count; i += stride) {
+    const uint64_t gi = (uint64_t)(a.first + i);
+    double z[3];
+    uint32_t spare;
+    pocs_normal3(seed, gi, (uint32_t)a.waypoint, POCS_STREAM_GMM, z, &spare);
+    // component draw (GM_Model.h:89-93): number of cumulative-weight entries below the uniform
+    const double uc = ((double)spare + 0.5) * 0x1p-32;
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) k += (s_par[j * POCS_PARAM_STRIDE + 9] < uc) ? 1 : 0;
+    const double* p = &s_par[k * POCS_PARAM_STRIDE];
+    // mvnrnd (glue_mvnrnd_meat.hpp:134-145): chol_lower * z + mean
+    const double x = fma(p[3], z[0], p[0]);
+    const double y = fma(p[5], z[1], fma(p[4], z[0], p[1]));
+    const double t = fma(p[8], z[2], fma(p[7], z[1], fma(p[6], z[0], p[2])));
+    const bool hit = pocs_pose_collides(x, y, t, &fp, s_obs, M);
+    if (STORE) {
+      a.x[i] = x; a.y[i] = y; a.th[i] = t;
+      a.flags[i] = hit ? (int16_t)1 : (int16_t)0;
+    }
+    const double fx = hit ? 0.0 : x, fy = hit ? 0.0 : y, ft = hit ? 0.0 : t;
+    const double m0 = fx, m1 = fy, m2 = ft;
+    const double m3 = fx * fx, m4 = fx * fy, m5 = fx * ft, m6 = fy * fy, m7 = fy * ft, m8 = ft * ft;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+      const bool sel = (k == kk);
+      nfree[kk] += (sel && !hit) ? 1u : 0u;
+      ncoll[kk] += (sel && hit) ? 1u : 0u;
+      acc[kk][0] += sel ? m0 : 0.0;
+      acc[kk][1] += sel ? m1 : 0.0;
+      acc[kk][2] += sel ? m2 : 0.0;
+      acc[kk][3] += sel ? m3 : 0.0;
+      acc[kk][4] += sel ? m4 : 0.0;
+      acc[kk][5] += sel ? m5 : 0.0;
+      acc[kk][6] += sel ? m6 : 0.0;
+      acc[kk][7] += sel ? m7 : 0.0;
+      acc[kk][8] += sel ? m8 : 0.0;
+    }
+  }
+
+  // wave butterflies -> one row per wave in LDS -> fixed-order sum over the 4 waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const unsigned nf = wave_sum_u32(nfree[k]);
+    const unsigned nc = wave_sum_u32(ncoll[k]);
+    if (lane == 0) { s_red[wave][k * POCS_NMOM] = (double)nf; s_red[wave][k * POCS_NMOM + 1] = (double)nc; }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const double v = wave_sum(acc[k][j]);
+      if (lane == 0) s_red[wave][k * POCS_NMOM + 2 + j] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < K * POCS_NMOM) {
+    double v = s_red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < POCS_BLOCK / 64; ++w) v += s_red[w][threadIdx.x];
+    a.partial[(size_t)blockIdx.x * (K * POCS_NMOM) + threadIdx.x] = v;
+  }
+}
+
+#define POCS_FIN_THREADS 1024
+__global__ __launch_bounds__(POCS_FIN_THREADS) void k_gmm_finalize(pocs_finalize_launch a) {
+  __shared__ double s_part[POCS_FIN_THREADS];
+  const int ncols = a.K * POCS_NMOM;
+  if (a.reduce_wp >= 0) {
+    // slice s of column c sums blocks s, s+S, s+2S, ... ; then the S slice sums are added in order
+    const int S = POCS_FIN_THREADS / ncols;
+    const int s = threadIdx.x / ncols, c = threadIdx.x - s * ncols;
+    double v = 0.0;
+    if (s < S)
+      for (int b = s; b < a.nblk; b += S) v += a.partial[(size_t)b * ncols + c];
+    s_part[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < ncols) {
+      double tot = s_part[threadIdx.x];
+      for (int q = 1; q < S; ++q) tot += s_part[q * ncols + threadIdx.x];
+      a.moments[(size_t)a.reduce_wp * ncols + threadIdx.x] = tot;
+    }
+    __syncthreads();
+    __threadfence_block();
+  }
+  if (a.advance_wp >= 0) {
+    const int w = a.advance_wp;
+    const size_t ss = (size_t)a.K * POCS_STATE_STRIDE, ps = (size_t)a.K * POCS_PARAM_STRIDE;
+    double* next = a.state + (size_t)w * ss;
+    double* param = a.param + (size_t)w * ps;
+    if ((int)threadIdx.x < a.K) {
+      const double* prev = (w == 0) ? next : a.state + (size_t)(w - 1) * ss;
+      const double* mom = (w == 0) ? nullptr : a.moments + (size_t)(w - 1) * ncols;
+      const double* ch = (w == 0) ? a.chain : a.chain + (size_t)(w - 1) * POCS_CHAIN_STRIDE;
+      pocs_gmm_advance_component(threadIdx.x, prev, mom, ch, ch + 3, ch + POCS_CHAIN_Z, a.sensor,
+                                 next, param);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) pocs_gmm_normalise(a.K, w > 0, next, param);
+  }
+}
+
+__global__ __launch_bounds__(POCS_BLOCK) void k_mc_init(pocs_mc_launch a) {
+  __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
+  __shared__ pocs_footprint s_fp;
+  __shared__ int s_M;
+  stage_env(a.env, s_obs, &s_fp, &s_M);
+  __syncthreads();
+  const uint64_t seed = a.hdr->seed;
+  const pocs_footprint fp = s_fp;
+  const int M = s_M;
+  const long long stride = (long long)gridDim.x * POCS_BLOCK;
+  for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < a.count; i += stride) {
+    double z[3];
+    uint32_t spare;
+    pocs_normal3(seed, (uint64_t)(a.first + i), 0u, POCS_STREAM_MCINIT, z, &spare);
+    const double x = fma(a.L0[0], z[0], a.mu0[0]);
+    const double y = fma(a.L0[2], z[1], fma(a.L0[1], z[0], a.mu0[1]));
+    const double t = fma(a.L0[5], z[2], fma(a.L0[4], z[1], fma(a.L0[3], z[0], a.mu0[2])));
+    a.x[i] = x; a.y[i] = y; a.th[i] = t;
+    a.hits[i] = pocs_pose_collides(x, y, t, &fp, s_obs, M) ? 1u : 0u;
+  }
+}
+
+__global__ __launch_bounds__(POCS_BLOCK) void k_mc_step(pocs_mc_launch a) {
+  __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
+  __shared__ pocs_footprint s_fp;
+  __shared__ int s_M;
+  stage_env(a.env, s_obs, &s_fp, &s_M);
+  __syncthreads();
+  const pocs_footprint fp = s_fp;
+  const int M = s_M;
+  const double* u = a.chain + (size_t)a.step * POCS_CHAIN_STRIDE + 6;
+  const double u0 = u[0], u1 = u[1], u2 = u[2];
+  const long long stride = (long long)gridDim.x * POCS_BLOCK;
+  for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < a.count; i += stride) {
+    const double x = a.x[i], y = a.y[i], t = a.th[i];
+    double sn, cs;
+    pocs_sincos(t + u0, &sn, &cs);
+    const double nx = fma(u1, cs, x);
+    const double ny = fma(u1, sn, y);
+    const double nt = pocs_wrap_angle(t + u0 + u2);
+    a.x[i] = nx; a.y[i] = ny; a.th[i] = nt;
+    if (pocs_pose_collides(nx, ny, nt, &fp, s_obs, M)) a.hits[i] += 1u;
+  }
+}
+
+__global__ __launch_bounds__(POCS_BLOCK) void k_mc_fused(pocs_mc_launch a) {
+  __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
+  __shared__ pocs_footprint s_fp;
+  __shared__ int s_M;
+  stage_env(a.env, s_obs, &s_fp, &s_M);
+  __syncthreads();
+  const uint64_t seed = a.hdr->seed;
+  const pocs_footprint fp = s_fp;
+  const int M = s_M;
+  const long long stride = (long long)gridDim.x * POCS_BLOCK;
+  for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < a.count; i += stride) {
+    double z[3];
+    uint32_t spare;
+    pocs_normal3(seed, (uint64_t)(a.first + i), 0u, POCS_STREAM_MCINIT, z, &spare);
+    double x = fma(a.L0[0], z[0], a.mu0[0]);
+    double y = fma(a.L0[2], z[1], fma(a.L0[1], z[0], a.mu0[1]));
+    double t = fma(a.L0[5], z[2], fma(a.L0[4], z[1], fma(a.L0[3], z[0], a.mu0[2])));
+    unsigned h = pocs_pose_collides(x, y, t, &fp, s_obs, M) ? 1u : 0u;
+    for (int s = 0; s < a.step; ++s) {
+      const double* u = a.chain + (size_t)s * POCS_CHAIN_STRIDE + 6;   // wave-uniform
+      const double u0 = u[0], u1 = u[1], u2 = u[2];
+      double sn, cs;
+      pocs_sincos(t + u0, &sn, &cs);
+      x = fma(u1, cs, x);
+      y = fma(u1, sn, y);
+      t = pocs_wrap_angle(t + u0 + u2);
+      h += pocs_pose_collides(x, y, t, &fp, s_obs, M) ? 1u : 0u;
+    }
+    a.x[i] = x; a.y[i] = y; a.th[i] = t;
+    a.hits[i] = h;
+  }
+}
+
+__global__ __launch_bounds__(POCS_BLOCK) void k_mc_count(const uint32_t* __restrict__ hits,
+                                                         long long count,
+                                                         unsigned long long* total) {
+  __shared__ unsigned s_w[POCS_BLOCK / 64];
+  unsigned c = 0;
+  const long long stride = (long long)gridDim.x * POCS_BLOCK;
+  for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < count; i += stride)
+    c += hits[i] > 0u ? 1u : 0u;
+  c = wave_sum_u32(c);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < POCS_BLOCK / 64; ++w) t += s_w[w];
+    if (t) atomicAdd(total, t);      // integer atomic: order independent, exact
+  }
+}
+
+template <int K>
+hipError_t launch_gmm_k(int nblk, const pocs_gmm_launch& a, hipStream_t s) {
+  if (a.store) hipLaunchKernelGGL((k_gmm_sample<K, true>), dim3(nblk), dim3(POCS_BLOCK), 0, s, a);
+  else         hipLaunchKernelGGL((k_gmm_sample<K, false>), dim3(nblk), dim3(POCS_BLOCK), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t pocs_launch_gmm_sample(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s) {
+  switch (K) {
+    case 1: return launch_gmm_k<1>(nblk, a, s);
+    case 2: return launch_gmm_k<2>(nblk, a, s);
+    case 3: return launch_gmm_k<3>(nblk, a, s);
+    case 4: return launch_gmm_k<4>(nblk, a, s);
+    case 5: return launch_gmm_k<5>(nblk, a, s);
+    case 6: return launch_gmm_k<6>(nblk, a, s);
+    case 7: return launch_gmm_k<7>(nblk, a, s);
+    case 8: return launch_gmm_k<8>(nblk, a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t pocs_launch_gmm_finalize(const pocs_finalize_launch& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_gmm_finalize, dim3(1), dim3(POCS_FIN_THREADS), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_mc_init, dim3(nblk), dim3(POCS_BLOCK), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t pocs_launch_mc_step(int nblk, const pocs_mc_launch& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_mc_step, dim3(nblk), dim3(POCS_BLOCK), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t pocs_launch_mc_fused(int nblk, const pocs_mc_launch& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_mc_fused, dim3(nblk), dim3(POCS_BLOCK), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t pocs_launch_mc_count(int nblk, const uint32_t* hits, long long count,
+                                unsigned long long* total, hipStream_t s) {
+  hipLaunchKernelGGL(k_mc_count, dim3(nblk), dim3(POCS_BLOCK), 0, s, hits, count, total);
+  return hipGetLastError();
+}

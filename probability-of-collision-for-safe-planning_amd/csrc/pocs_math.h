@@ -1,0 +1,168 @@
+// pocs_math.h -- numerics shared by the host chain and the HIP kernels (product code).
+//
+// Everything here is `__host__ __device__` and written so that the host build and the
+// gfx950 build execute the *same sequence of IEEE-754 binary64 operations*:
+//   * the translation units are compiled with -ffp-contract=off, every fused multiply-add
+//     is an explicit fma();
+//   * only +, -, *, /, sqrt, fma, rint and integer ops are used (all correctly rounded on
+//     both sides), never a vendor libm transcendental.
+// The spec ("POCS numerics v1") is written out in DESIGN.md section 4; the CPU oracle under
+// oracle/ holds an independent plain-C restatement of the same spec and is never linked here.
+//
+// What this replaces in the reference: Armadillo's RNG + mvnrnd (GM_Model.h:83-116,
+// MCSimulator.h:51-53,287-297; armadillo_bits/arma_rng.hpp:324-432) and libm cos/sin
+// (MCSimulator.h:312-313,424-425).  The reference seeds from the clock/urandom
+// (MCSimulator.h:141, GM_Model.h:53-54) so no stream of its own can be reproduced; ours is
+// counter based (Philox4x32-10) so any (seed, index, waypoint) draw is a pure function.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define POCS_HD __host__ __device__ __forceinline__
+#else
+#define POCS_HD inline
+#endif
+
+// ----------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+// SC'11).  Counter = 4 x u32, key = 2 x u32.
+// ----------------------------------------------------------------------------------------
+struct pocs_u32x4 { uint32_t x, y, z, w; };
+
+POCS_HD pocs_u32x4 pocs_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                      uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  pocs_u32x4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+  return o;
+}
+
+// Stream ids (counter word 3 = stream << 16 | slot).
+#define POCS_STREAM_CHAIN 1u   // host chain: odometry + observation noise (MCSimulator.h:391-410,383-387)
+#define POCS_STREAM_MCINIT 2u  // initial particle cloud                   (MCSimulator.h:287-297)
+#define POCS_STREAM_GMM 3u     // mixture samples                          (GM_Model.h:83-116)
+
+POCS_HD pocs_u32x4 pocs_draw(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stream,
+                             uint32_t slot) {
+  return pocs_philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), waypoint,
+                            (stream << 16) | slot, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// ----------------------------------------------------------------------------------------
+// log(x) for normal positive x.  Argument reduction x = 2^k (1+f), sqrt(1/2) < 1+f <= sqrt(2);
+// s = f/(2+f); log(1+f) = f - f^2/2 + s (f^2/2 + R(s^2)), R = the classic degree-14 minimax
+// polynomial in s (coefficients Lg1..Lg7 as published with Sun's fdlibm e_log.c).
+// ----------------------------------------------------------------------------------------
+POCS_HD double pocs_log(double x) {
+  union { double d; uint64_t u; } b; b.d = x;
+  uint32_t hx = (uint32_t)(b.u >> 32);
+  int k = (int)(hx >> 20) - 1023;
+  hx &= 0x000fffffu;
+  const uint32_t i = (hx + 0x95f64u) & 0x100000u;   // 1+f > sqrt(2)  ->  halve, k += 1
+  b.u = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (b.u & 0xffffffffull);
+  k += (int)(i >> 20);
+  const double f = b.d - 1.0;
+  const double dk = (double)k;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
+                            3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                   2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  // dk*ln2_hi - ((hfsq - (s*(hfsq+R) + dk*ln2_lo)) - f)
+  return dk * 6.93147180369123816490e-01 -
+         ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+
+// sin / cos on [-pi/4, pi/4] (degree-13 / degree-14 minimax kernels, coefficients as published
+// with fdlibm k_sin.c / k_cos.c), Horner form on z = x^2 with explicit fma.
+POCS_HD double pocs_ksin(double x) {
+  const double z = x * x;
+  double r = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  r = fma(z, r, 2.75573137070700676789e-06);
+  r = fma(z, r, -1.98412698298579493134e-04);
+  r = fma(z, r, 8.33333333332248946124e-03);
+  r = fma(z, r, -1.66666666666666324348e-01);
+  return fma(z * x, r, x);
+}
+POCS_HD double pocs_kcos(double x) {
+  const double z = x * x;
+  double r = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  r = fma(z, r, -2.75573143513906633035e-07);
+  r = fma(z, r, 2.48015872894767294178e-05);
+  r = fma(z, r, -1.38888888888741095749e-03);
+  r = fma(z, r, 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  return w + (((1.0 - w) - hz) + (z * z) * r);
+}
+
+// sin and cos of an arbitrary angle |x| < 2^20: three-step Cody-Waite reduction by pi/2
+// (33+33+53 bit split of pi/2), then the kernels above.  Absolute error < 2 ulp(1).
+POCS_HD void pocs_sincos(double x, double* sn, double* cs) {
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  const int n = (int)fn;
+  double r = x - fn * 1.57079632673412561417e+00;
+  r = r - fn * 6.07710050630396597660e-11;
+  r = r - fn * 2.02226624879595063154e-21;
+  const double ks = pocs_ksin(r), kc = pocs_kcos(r);
+  const double a = (n & 1) ? kc : ks;     // |sin|-like term
+  const double b = (n & 1) ? ks : kc;     // |cos|-like term
+  *sn = (n & 2) ? -a : a;
+  *cs = ((n + 1) & 2) ? -b : b;
+}
+
+// sin and cos of 2*pi*t for t = w * 2^-32 given as the 32-bit integer w: the top three bits
+// select the octant, the low 29 bits give the position inside it; no range reduction error.
+POCS_HD void pocs_sincos_2pi_u32(uint32_t w, double* sn, double* cs) {
+  const uint32_t q = w >> 29;
+  const uint32_t m = w & 0x1fffffffu;
+  const uint32_t mm = (q & 1u) ? (0x20000000u - m) : m;            // odd octant: mirror
+  const double phi = ((double)mm * 0x1p-29) * 7.85398163397448279e-01;   // in [0, pi/4]
+  const double ks = pocs_ksin(phi), kc = pocs_kcos(phi);
+  const bool swap = ((q + 1u) & 2u) != 0u;                          // octants 1,2,5,6
+  const double a = swap ? kc : ks;                                  // |sin|
+  const double b = swap ? ks : kc;                                  // |cos|
+  *sn = (q & 4u) ? -a : a;                                          // octants 4..7
+  *cs = ((q + 2u) & 4u) ? -b : b;                                   // octants 2..5
+}
+
+// One Box-Muller pair from three words of a Philox draw:
+//   u = (((w1:w0) >> 11) + 1) * 2^-53 in (0,1],  radius = sqrt(-2 log u),  angle = 2 pi w2 2^-32.
+POCS_HD void pocs_normal_pair(uint32_t w0, uint32_t w1, uint32_t w2, double* n0, double* n1) {
+  const uint64_t a = ((((uint64_t)w1) << 32) | (uint64_t)w0) >> 11;
+  const double u = (double)(a + 1ull) * 0x1p-53;
+  const double rad = sqrt(-2.0 * pocs_log(u));
+  double sn, cs;
+  pocs_sincos_2pi_u32(w2, &sn, &cs);
+  *n0 = rad * cs;
+  *n1 = rad * sn;
+}
+
+// The three standard normals (+ one spare uniform word) that belong to (seed, index, waypoint)
+// on a stream: slot 0 -> z0, z1 and the spare word; slot 1 -> z2.
+POCS_HD void pocs_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stream,
+                          double z[3], uint32_t* spare) {
+  const pocs_u32x4 a = pocs_draw(seed, index, waypoint, stream, 0u);
+  const pocs_u32x4 b = pocs_draw(seed, index, waypoint, stream, 1u);
+  double unused;
+  pocs_normal_pair(a.x, a.y, a.z, &z[0], &z[1]);
+  pocs_normal_pair(b.x, b.y, b.z, &z[2], &unused);
+  *spare = a.w;
+}

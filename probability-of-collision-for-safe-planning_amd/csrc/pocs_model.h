@@ -1,0 +1,219 @@
+// pocs_model.h -- the O(1)-per-waypoint estimator math (product code, host + device).
+//
+// Each function names the reference function it stands in for (file:line under
+// /root/reference/mcsimplugin/).  3x3 matrices are row-major double[9].  Matrix products keep
+// the reference's association, (A*B)*C, and a left-to-right three-term inner sum; no operation
+// is contracted (the TU is built with -ffp-contract=off and these use no fma on purpose).
+// Used by: the host chain (pocs_host.hip) and the per-component device update inside
+// k_gmm_finalize (pocs_kernels.hip).
+#pragma once
+#include "pocs_math.h"
+
+#define POCS_MAX_LANDMARKS 32
+#define POCS_MAX_GAUSSIANS 8
+#define POCS_NMOM 11           // per component: nFree nColl Sx Sy St Sxx Sxy Sxt Syy Syt Stt
+#define POCS_STATE_STRIDE 16   // per component: mean[3] cov[9] weight alive pad pad
+#define POCS_PARAM_STRIDE 12   // per component: mean[3] L00 L10 L11 L20 L21 L22 cumw alive pad
+
+struct pocs_sensor {            // landmarks + sensor variance (MCSimulator.h:97-101)
+  double Q;
+  int L;
+  int pad;
+  double lx[POCS_MAX_LANDMARKS];
+  double ly[POCS_MAX_LANDMARKS];
+};
+
+// angleWrap / roundAngle, MCSimulator.h:56-69: while-loops into [0, 2pi]; exactly 2pi is kept.
+// Guard (ours): non-finite or absurd input is returned unchanged instead of looping.
+POCS_HD double pocs_wrap_angle(double a) {
+  const double TWO_PI = 2 * 3.14159265358979323846;
+  if (!(fabs(a) <= 1.0e9)) return a;
+  while (a < 0) a += TWO_PI;
+  while (a > TWO_PI) a -= TWO_PI;
+  return a;
+}
+
+// prediction(), MCSimulator.h:413-431 (and moveParticles :300-322, same formula per particle).
+POCS_HD void pocs_motion(const double x[3], const double u[3], double out[3]) {
+  double sn, cs;
+  pocs_sincos(x[2] + u[0], &sn, &cs);
+  out[0] = fma(u[1], cs, x[0]);
+  out[1] = fma(u[1], sn, x[1]);
+  out[2] = pocs_wrap_angle(x[2] + u[0] + u[2]);
+}
+
+POCS_HD void pocs_mat3_mul(const double* A, const double* B, double* C) {       // C = A*B
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      C[3 * i + j] = (A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j]) + A[3 * i + 2] * B[6 + j];
+}
+POCS_HD void pocs_mat3_mul_bt(const double* A, const double* B, double* C) {    // C = A*B^T
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      C[3 * i + j] = (A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1]) + A[3 * i + 2] * B[3 * j + 2];
+}
+
+// EKFpredict(), MCSimulator.h:868-881, with generateG_EKF :517-529, generateV_EKF :453-468
+// (V is copied as written: row 2 = [1 0 1]) and M = diag(Md) from generateM_EKF :495-513.
+POCS_HD void pocs_ekf_predict(const double mu[3], const double S[9], const double u[3],
+                              const double Md[3], double pmu[3], double pS[9]) {
+  double sn, cs;
+  pocs_sincos(mu[2] + u[0], &sn, &cs);
+  const double G[9] = {1, 0, -u[1] * sn, 0, 1, u[1] * cs, 0, 0, 1};
+  const double V[9] = {-u[1] * sn, cs, 0, u[1] * cs, sn, 0, 1, 0, 1};
+  const double M[9] = {Md[0], 0, 0, 0, Md[1], 0, 0, 0, Md[2]};
+  double T[9], R[9], GS[9];
+  pocs_mat3_mul(V, M, T);
+  pocs_mat3_mul_bt(T, V, R);
+  pocs_mat3_mul(G, S, GS);
+  pocs_mat3_mul_bt(GS, G, pS);
+  for (int i = 0; i < 9; ++i) pS[i] = pS[i] + R[i];
+  pmu[0] = fma(u[1], cs, mu[0]);
+  pmu[1] = fma(u[1], sn, mu[1]);
+  pmu[2] = pocs_wrap_angle(mu[2] + u[0] + u[2]);
+}
+
+// EKFupdate(), MCSimulator.h:883-929 (makeHRow :470-492, observation :368-381): one scalar
+// range update per landmark, in landmark order, in place; no angle wrap afterwards.
+POCS_HD void pocs_ekf_update(double mu[3], double S[9], const double* z, const pocs_sensor* sen) {
+  for (int l = 0; l < sen->L; ++l) {
+    const double dx = mu[0] - sen->lx[l];
+    const double dy = mu[1] - sen->ly[l];
+    const double q = dx * dx + dy * dy;
+    const double sq = sqrt(q);
+    const double H0 = -(sen->lx[l] - mu[0]) / sq;
+    const double H1 = -(sen->ly[l] - mu[1]) / sq;
+    // S = H Sigma H^T + Q   (1x1);  (H*Sigma) first, then the dot with H
+    const double hs0 = H0 * S[0] + H1 * S[3];
+    const double hs1 = H0 * S[1] + H1 * S[4];
+    const double sinn = (hs0 * H0 + hs1 * H1) + sen->Q;
+    const double sinv = 1.0 / sinn;
+    // K = (Sigma H^T) * S^-1
+    const double K0 = (S[0] * H0 + S[1] * H1) * sinv;
+    const double K1 = (S[3] * H0 + S[4] * H1) * sinv;
+    const double K2 = (S[6] * H0 + S[7] * H1) * sinv;
+    const double innov = z[l] - sq;
+    mu[0] = mu[0] + K0 * innov;
+    mu[1] = mu[1] + K1 * innov;
+    mu[2] = mu[2] + K2 * innov;
+    const double A[9] = {1.0 - K0 * H0, 0.0 - K0 * H1, 0, 0.0 - K1 * H0, 1.0 - K1 * H1, 0,
+                         0.0 - K2 * H0, 0.0 - K2 * H1, 1};
+    double N[9];
+    pocs_mat3_mul(A, S, N);
+    for (int i = 0; i < 9; ++i) S[i] = N[i];
+  }
+}
+
+// chol(C, "lower") as used by mvnrnd (armadillo_bits/glue_mvnrnd_meat.hpp:92-147 -> LAPACK
+// potrf, which reads the lower triangle only).  Returns 0 on a non-positive pivot; the
+// reference's eigen-decomposition fallback for that case (:100-132) is not reproduced -- the
+// caller retires the component instead (DESIGN.md "degenerate cases").
+POCS_HD int pocs_chol3_lower(const double S[9], double L[6]) {
+  const double d0 = S[0];
+  if (!(d0 > 0.0)) return 0;
+  const double l00 = sqrt(d0);
+  const double l10 = S[3] / l00;
+  const double l20 = S[6] / l00;
+  const double d1 = S[4] - l10 * l10;
+  if (!(d1 > 0.0)) return 0;
+  const double l11 = sqrt(d1);
+  const double l21 = (S[7] - l20 * l10) / l11;
+  const double d2 = (S[8] - l20 * l20) - l21 * l21;
+  if (!(d2 > 0.0)) return 0;
+  L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = sqrt(d2);
+  return 1;
+}
+
+// The per-component tail of truncateGMM(), MCSimulator.h:592-605: mean(free,1) and
+// cov(free^T) with Armadillo's single-pass form (op_cov_meat.hpp:26-53):
+//   out = A^T A;  out -= acc^T acc / N;  out /= (N-1).
+// mom = the 11 accumulated moments of one component.  Returns 0 when fewer than two samples
+// survived (the reference has no defined behaviour there).
+POCS_HD int pocs_truncated_moments(const double* mom, double mean[3], double cov[9]) {
+  const double n = mom[0];
+  if (!(n >= 2.0)) return 0;
+  const double sx = mom[2], sy = mom[3], st = mom[4];
+  mean[0] = sx / n; mean[1] = sy / n; mean[2] = st / n;
+  const double nm1 = n - 1.0;
+  const double cxx = (mom[5] - (sx * sx) / n) / nm1;
+  const double cxy = (mom[6] - (sx * sy) / n) / nm1;
+  const double cxt = (mom[7] - (sx * st) / n) / nm1;
+  const double cyy = (mom[8] - (sy * sy) / n) / nm1;
+  const double cyt = (mom[9] - (sy * st) / n) / nm1;
+  const double ctt = (mom[10] - (st * st) / n) / nm1;
+  cov[0] = cxx; cov[1] = cxy; cov[2] = cxt;
+  cov[3] = cxy; cov[4] = cyy; cov[5] = cyt;
+  cov[6] = cxt; cov[7] = cyt; cov[8] = ctt;
+  return 1;
+}
+
+// One waypoint of the mixture bookkeeping, split so the device can run one component per
+// thread: truncateGMM's tail (:592-629: truncated mean/cov; weights = nFree_k / sum nFree via
+// normalise(.,1,1), armadillo_bits/op_normalise_meat.hpp:107-121), then the per-component
+// EKFpredict/EKFupdate of EKF_GaussProp (:766-771, :804-812) for the next waypoint, then the
+// Cholesky factor and the cumulative weight table the sampler needs.
+//   prev   : K x POCS_STATE_STRIDE, the mixture that was sampled at the previous waypoint
+//   mom    : K x POCS_NMOM, the (globally reduced) moments of that waypoint; NULL at waypoint 0
+//   next   : K x POCS_STATE_STRIDE out, the mixture to sample at this waypoint
+//   param  : K x POCS_PARAM_STRIDE out, sampler parameters for this waypoint
+// A component with < 2 survivors, or whose covariance is not positive definite, is retired:
+// weight 0, alive 0, state frozen.
+POCS_HD void pocs_gmm_advance_component(int k, const double* prev, const double* mom,
+                                        const double* u, const double* Md, const double* z,
+                                        const pocs_sensor* sen, double* next, double* param) {
+  const double* p = prev + k * POCS_STATE_STRIDE;
+  double* o = next + k * POCS_STATE_STRIDE;
+  double mean[3], cov[9];
+  double alive = p[13];
+  double weight = p[12];
+  for (int i = 0; i < 3; ++i) mean[i] = p[i];
+  for (int i = 0; i < 9; ++i) cov[i] = p[3 + i];
+  if (mom) {
+    weight = 0.0;
+    if (alive != 0.0) {
+      double tm[3], tc[9];
+      if (pocs_truncated_moments(mom + k * POCS_NMOM, tm, tc)) {
+        double pm[3], pc[9];
+        pocs_ekf_predict(tm, tc, u, Md, pm, pc);
+        pocs_ekf_update(pm, pc, z, sen);
+        for (int i = 0; i < 3; ++i) mean[i] = pm[i];
+        for (int i = 0; i < 9; ++i) cov[i] = pc[i];
+        weight = mom[k * POCS_NMOM];       // nFree_k, normalised by pocs_gmm_normalise
+      } else {
+        alive = 0.0;
+      }
+    }
+  }
+  double L[6] = {0, 0, 0, 0, 0, 0};
+  if (alive != 0.0 && !pocs_chol3_lower(cov, L)) { alive = 0.0; weight = 0.0; }
+  for (int i = 0; i < 3; ++i) o[i] = mean[i];
+  for (int i = 0; i < 9; ++i) o[3 + i] = cov[i];
+  o[12] = weight; o[13] = alive; o[14] = 0.0; o[15] = 0.0;
+  double* q = param + k * POCS_PARAM_STRIDE;
+  for (int i = 0; i < 3; ++i) q[i] = mean[i];
+  for (int i = 0; i < 6; ++i) q[3 + i] = L[i];
+  q[9] = 0.0; q[10] = alive; q[11] = 0.0;
+}
+
+// Second half: weights and the sampler's selection table.  `renorm` = 1 when the weights in
+// `next` are raw survivor counts (every waypoint but the first).
+POCS_HD void pocs_gmm_normalise(int K, int renorm, double* next, double* param) {
+  double wsum = 0.0;
+  for (int k = 0; k < K; ++k) wsum += next[k * POCS_STATE_STRIDE + 12];
+  // normalise(collisionCounts,1,1).row(1): divide by the L1 norm, a zero norm divides by 1.
+  const double den = (wsum != 0.0) ? wsum : 1.0;
+  int last_alive = -1;
+  for (int k = 0; k < K; ++k) {
+    double* o = next + k * POCS_STATE_STRIDE;
+    if (renorm) o[12] = o[12] / den;
+    if (o[13] != 0.0 && o[12] > 0.0) last_alive = k;
+  }
+  double cum = 0.0;
+  for (int k = 0; k < K; ++k) {
+    cum += next[k * POCS_STATE_STRIDE + 12];
+    // selection rule: component = number of table entries strictly below the uniform draw;
+    // entries from the last live component on are pinned above 1 so rounding never selects a
+    // retired component.
+    param[k * POCS_PARAM_STRIDE + 9] = (k >= last_alive) ? 2.0 : cum;
+  }
+}

@@ -1,0 +1,102 @@
+"""Pins of the oracle against data the reference itself holds (CPU only).
+
+ * odometry.dat == inverseOdometry(trajectory.dat) and prediction() lands on the next waypoint:
+   a free known-answer test for MCSimulator.h:413-449.
+ * armadillo-8.400.0/tests/fn_cov.cpp:35-74 ("fn_cov_2"): known-answer covariance matrix for
+   op_cov (the formula truncateGMM relies on, MCSimulator.h:598).
+ * published statistics of finalpaper/analysis (Table I) only as a sanity band -- the numbers
+   embed OpenRAVE's checker, which is not in the reference tree ("parity unpinned").
+"""
+import math
+
+import numpy as np
+
+
+def test_bundled_plan_shape_and_facts(plan):
+    traj, odom = plan["traj"], plan["odom"]
+    assert traj.shape == (56, 3) and odom.shape == (55, 3)           # MCSimulation.py:184
+    assert traj[0, 0] == -3.4 and traj[0, 1] == -1.4 and traj[0, 2] == 0.0
+    assert math.copysign(1.0, traj[0, 2]) == -1.0                     # stored as negative zero
+    assert np.allclose(traj[-1], [2.6, -1.3, -math.pi / 2])           # hw2_astar.py:71 goal
+    assert odom[:, [0, 2]].min() >= 0 and odom[:, [0, 2]].max() < 2 * math.pi
+    steps = np.round(odom[:, 1], 4)
+    assert set(steps) <= {0.1118, 0.15, 0.2121}
+
+
+def test_inverse_odometry_reproduces_odometry_dat(orc, plan):
+    traj, odom = plan["traj"], plan["odom"]
+    worst = 0.0
+    for i in range(len(odom)):
+        u = orc.inverse_odometry(traj[i], traj[i + 1])
+        worst = max(worst, np.max(np.abs(u - odom[i])))
+    assert worst <= 1e-15, worst
+
+
+def test_prediction_lands_on_next_waypoint(orc, plan):
+    traj, odom = plan["traj"], plan["odom"]
+    for i in range(len(odom)):
+        nxt = orc.prediction(traj[i], odom[i])
+        assert abs(nxt[0] - traj[i + 1, 0]) < 5e-16 and abs(nxt[1] - traj[i + 1, 1]) < 5e-16
+        d = (nxt[2] - traj[i + 1, 2]) % (2 * math.pi)
+        assert min(d, 2 * math.pi - d) < 1e-14
+
+
+def test_python_plan_helpers_agree(pocs, plan):
+    od = pocs.planio.path_odometry(plan["traj"])
+    assert np.max(np.abs(od - plan["odom"])) <= 1e-15
+
+
+FN_COV_A = np.array([[-0.78838, 0.69298, 0.41084, 0.90142],
+                     [0.49345, -0.12020, 0.78987, 0.53124],
+                     [0.73573, 0.52104, -0.22263, 0.40163]])
+FN_COV_AA = np.array([[0.670783, -0.191509, -0.120822, -0.211274],
+                      [-0.191509, 0.183669, -0.141426, 0.050641],
+                      [-0.120822, -0.141426, 0.261684, 0.051254],
+                      [-0.211274, 0.050641, 0.051254, 0.067270]])
+
+
+def test_cov_matches_armadillo_known_answer(orc):
+    # rows = observations, columns = variables; our routine handles 3 variables at a time
+    for cols in ([0, 1, 2], [1, 2, 3], [0, 2, 3]):
+        mean, cov = orc.cov_mean(FN_COV_A[:, cols])
+        assert np.sum(np.abs(cov - FN_COV_AA[np.ix_(cols, cols)])) < 5e-6
+        assert np.allclose(mean, FN_COV_A[:, cols].mean(axis=0), atol=1e-15)
+
+
+def test_cov_is_the_single_pass_n_minus_1_form(orc):
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(257, 3)) * [0.03, 0.03, 0.03] + [-3.4, -1.4, 0.0]
+    mean, cov = orc.cov_mean(X)
+    assert np.allclose(cov, np.cov(X.T), rtol=1e-9, atol=1e-15)
+    s = X.sum(axis=0)
+    want = (X.T @ X - np.outer(s, s) / len(X)) / (len(X) - 1)
+    assert np.allclose(cov, want, rtol=1e-9, atol=1e-16)   # same formula, numpy sums in another order
+
+
+def test_normalise_l1_and_zero_norm(orc):
+    assert np.allclose(orc.normalise_l1([2.0, 6.0, 2.0]), [0.2, 0.6, 0.2])
+    assert np.all(orc.normalise_l1([0.0, 0.0, 0.0]) == 0.0)           # zero norm divides by 1
+
+
+def test_chol_is_lower_and_reads_lower_triangle(orc):
+    rng = np.random.default_rng(6)
+    for _ in range(50):
+        B = rng.normal(size=(3, 3))
+        S = B @ B.T + 1e-3 * np.eye(3)
+        ok, L6 = orc.chol3_lower(S)
+        assert ok
+        L = np.array([[L6[0], 0, 0], [L6[1], L6[2], 0], [L6[3], L6[4], L6[5]]])
+        assert np.allclose(L @ L.T, S, rtol=1e-13, atol=1e-15)
+        assert np.allclose(L, np.linalg.cholesky(S), rtol=1e-12, atol=1e-15)
+        S2 = S.copy(); S2[0, 1] += 0.3; S2[1, 2] -= 0.2                # upper triangle is ignored
+        assert np.array_equal(orc.chol3_lower(S2)[1], L6)
+    assert orc.chol3_lower(np.diag([1.0, -1.0, 1.0]))[0] == 0
+
+
+def test_published_numbers_are_a_sanity_band_only(orc, plan, env):
+    """Table I (ajaay_paper.tex:874-877): MC 0.93 > GMM 0.64, both in (0.4, 1).  Our collision
+    model is not OpenRAVE's, so only the coarse ordering/band is asserted ("parity unpinned")."""
+    cfg = orc.config(plan, env, K=3)
+    mc = [orc.run_mc(cfg, 100 + s, 2000)[0] / 2000.0 for s in range(6)]
+    gm = [orc.run_gmm(cfg, 100 + s, 2000)["prob"] for s in range(6)]
+    assert 0.05 < np.mean(gm) <= 1.0 and 0.05 < np.mean(mc) <= 1.0

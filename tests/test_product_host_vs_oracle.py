@@ -1,0 +1,169 @@
+"""The product's host+device inline functions (compiled for the host by tests/host_harness.cpp)
+against the independent oracle restatement -- bit for bit where the numerics spec fixes the
+operation order (CPU only; the GPU versions of the same checks live in test_gpu_parity.py)."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from conftest import dp
+
+
+def test_philox_bitwise(hh, orc):
+    rng = np.random.default_rng(11)
+    for _ in range(500):
+        ctr = [int(v) for v in rng.integers(0, 2 ** 32, 4)]
+        key = [int(v) for v in rng.integers(0, 2 ** 32, 2)]
+        o = (C.c_uint32 * 4)()
+        hh.hh_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), o)
+        assert list(o) == orc.philox(ctr, key)
+
+
+def test_math_bitwise(hh, orc):
+    rng = np.random.default_rng(12)
+    for x in rng.random(5000):
+        assert hh.hh_log(float(x)) == orc.log(float(x))
+    s, c = C.c_double(), C.c_double()
+    for x in np.concatenate([rng.uniform(-20, 20, 5000), rng.uniform(-1e5, 1e5, 500)]):
+        hh.hh_sincos(C.c_double(x), C.byref(s), C.byref(c))
+        assert (s.value, c.value) == orc.sincos(float(x))
+    for w in rng.integers(0, 2 ** 32, 5000):
+        hh.hh_sincos_2pi_u32(C.c_uint32(int(w)), C.byref(s), C.byref(c))
+        assert (s.value, c.value) == orc.sincos_2pi_u32(int(w))
+
+
+def test_normal3_bitwise(hh, orc):
+    z = (C.c_double * 3)()
+    sp = C.c_uint32()
+    for idx in list(range(200)) + [2 ** 32 - 1, 2 ** 32, 2 ** 40 + 3]:
+        for wp, stream in ((0, 2), (3, 3), (55, 3), (499, 3)):
+            hh.hh_normal3(C.c_uint64(0x5EED0001), C.c_uint64(idx), C.c_uint32(wp), C.c_uint32(stream), z, C.byref(sp))
+            want_z, want_sp = orc.normal3(0x5EED0001, idx, wp, stream)
+            assert list(z) == want_z and sp.value == want_sp
+
+
+def test_motion_and_wrap_bitwise(hh, orc, plan):
+    rng = np.random.default_rng(13)
+    o = np.zeros(3)
+    for i in range(len(plan["odom"])):
+        x = plan["traj"][i] + rng.normal(0, 0.05, 3)
+        u = plan["odom"][i] + rng.normal(0, 0.01, 3)
+        hh.hh_motion(dp(np.ascontiguousarray(x)), dp(np.ascontiguousarray(u)), dp(o))
+        assert np.array_equal(o, orc.prediction(x, u))
+    for a in [0.0, -0.0, 2 * math.pi, -1e-9, 7.5, -13.0, 1e10, float("inf")]:
+        assert hh.hh_wrap(a) == orc.wrap_angle(a) or (math.isnan(hh.hh_wrap(a)) and math.isnan(orc.wrap_angle(a)))
+
+
+def _rand_spd(rng, scale=1e-3):
+    B = rng.normal(size=(3, 3))
+    return (B @ B.T + 0.5 * np.eye(3)) * scale
+
+
+def test_ekf_predict_update_chol_bitwise(hh, orc, pocs):
+    rng = np.random.default_rng(14)
+    lm = np.array(pocs.DEFAULTS["landmarks"], dtype=np.float64)
+    lx, ly = np.ascontiguousarray(lm[0]), np.ascontiguousarray(lm[1])
+    for _ in range(200):
+        mu = np.array([rng.uniform(-3, 3), rng.uniform(-1.5, 1.5), rng.uniform(0, 6.28)])
+        S = _rand_spd(rng)
+        u = np.array([rng.uniform(0, 6.28), rng.uniform(0.05, 0.3), rng.uniform(0, 6.28)])
+        Md = np.abs(rng.normal(size=3)) * 1e-5
+        pm, pS = np.zeros(3), np.zeros(9)
+        hh.hh_ekf_predict(dp(mu), dp(np.ascontiguousarray(S.ravel())), dp(u), dp(Md), dp(pm), dp(pS))
+        wm, wS = orc.ekf_predict(mu, S, u, Md)
+        assert np.array_equal(pm, wm) and np.array_equal(pS.reshape(3, 3), wS)
+        z = np.hypot(mu[0] - lx, mu[1] - ly) + rng.normal(0, 0.2, len(lx))
+        m2, S2 = pm.copy(), pS.copy()
+        hh.hh_ekf_update(dp(m2), dp(S2), dp(z), len(lx), dp(lx), dp(ly), C.c_double(0.04))
+        wm2, wS2 = orc.ekf_update(wm, wS, z, lx, ly, 0.04)
+        assert np.array_equal(m2, wm2) and np.array_equal(S2.reshape(3, 3), wS2)
+        L = np.zeros(6)
+        ok = hh.hh_chol(dp(S2), dp(L))
+        wok, wL = orc.chol3_lower(wS2)
+        assert ok == wok and np.array_equal(L, wL)
+
+
+def test_collision_predicate_identical(hh, orc, env):
+    rng = np.random.default_rng(15)
+    fp = np.ascontiguousarray(env["footprint"], dtype=np.float64)
+    rot = np.array([[0.5, 0.2, 0.3, 0.6, 1.0471975511965976], [-1.0, -0.5, 0.2, 0.9, -0.7],
+                    [2.0, 1.0, 0.4, 0.1, 1.5707963267948966]])
+    for boxes in (env["boxes"], np.vstack([env["boxes"], rot]), rot[:1]):
+        b = np.ascontiguousarray(boxes, dtype=np.float64)
+        n_hit = 0
+        for _ in range(6000):
+            x, y, th = rng.uniform(-4.2, 4.2), rng.uniform(-2.2, 2.2), rng.uniform(-7, 7)
+            got = hh.hh_collides(C.c_double(x), C.c_double(y), C.c_double(th), dp(fp), dp(b), len(b))
+            assert bool(got) == orc.collides(x, y, th, fp, b)
+            n_hit += got
+        assert 0 < n_hit < 6000
+
+
+def test_collision_predicate_geometry(orc, env):
+    """Independent check of the predicate itself with shapely-free geometry: corner sampling."""
+    fp = [0, 0, 0.334, 0.334]
+    wall = np.array([[0.8, -0.565, 0.1, 1.235, 0.0]])
+    # axis-aligned robot: overlaps iff |dx| <= 0.434 and |dy| <= 1.569
+    assert orc.collides(0.8 - 0.433, -0.565, 0.0, fp, wall)
+    assert not orc.collides(0.8 - 0.435, -0.565, 0.0, fp, wall)
+    assert orc.collides(0.8, -0.565 + 1.568, 0.0, fp, wall)
+    assert not orc.collides(0.8, -0.565 + 1.570, 0.0, fp, wall)
+    # rotated 45 deg the square reaches 0.334*sqrt(2) = 0.4723 along x
+    assert orc.collides(0.8 - 0.1 - 0.47, -0.565, math.pi / 4, fp, wall)
+    assert not orc.collides(0.8 - 0.1 - 0.475, -0.565, math.pi / 4, fp, wall)
+    # the doorway of pr2test2 (y in (0.67, 1.5)): the nominal crossing pose is free, off-centre is not
+    assert not orc.collides(0.8, 1.05, 0.0, fp, env["boxes"])
+    assert orc.collides(0.8, 0.95, 0.0, fp, env["boxes"])
+    assert orc.collides(0.8, 1.2, 0.0, fp, env["boxes"])
+    # footprint offset moves the box with the heading
+    assert orc.collides(0.0, 0.0, 0.0, [0.5, 0, 0.1, 0.1], np.array([[0.5, 0.0, 0.05, 0.05, 0.3]]))
+    assert not orc.collides(0.0, 0.0, math.pi, [0.5, 0, 0.1, 0.1], np.array([[0.5, 0.0, 0.05, 0.05, 0.3]]))
+
+
+def test_gmm_advance_matches_oracle(hh, orc, plan, env, pocs):
+    cfg = orc.config(plan, env, K=3)
+    lm = np.array(pocs.DEFAULTS["landmarks"], dtype=np.float64)
+    lx, ly = np.ascontiguousarray(lm[0]), np.ascontiguousarray(lm[1])
+    chain = orc.host_chain(cfg, 77)
+    state = orc.gmm_initial_state(cfg)
+    nxt, par = np.zeros((3, 16)), np.zeros((3, 12))
+    hh.hh_gmm_advance(3, dp(state), None, None, None, None, 8, dp(lx), dp(ly), C.c_double(pocs.DEFAULTS["Q"]), dp(nxt), dp(par))
+    want = orc.gmm_advance(cfg, state, None)
+    assert np.array_equal(nxt[:, :14], want[:, :14])
+    state = want
+    for w in range(6):
+        mom = orc.gmm_waypoint(cfg, 77, w, state, 0, 500)
+        want = orc.gmm_advance(cfg, state, mom, chain["applied"][w], chain["Mdiag"][w], chain["z"][w])
+        hh.hh_gmm_advance(3, dp(state), dp(mom), dp(np.ascontiguousarray(chain["applied"][w])),
+                          dp(np.ascontiguousarray(chain["Mdiag"][w])), dp(np.ascontiguousarray(chain["z"][w])),
+                          8, dp(lx), dp(ly), C.c_double(pocs.DEFAULTS["Q"]), dp(nxt), dp(par))
+        assert np.array_equal(nxt[:, :14], want[:, :14])
+        # sampler parameters: mean, Cholesky factor, selection table
+        for k in range(3):
+            ok, L = orc.chol3_lower(want[k, 3:12])
+            assert ok and np.array_equal(par[k, 3:9], L) and np.array_equal(par[k, 0:3], want[k, 0:3])
+        assert par[2, 9] == 2.0 and par[0, 9] == want[0, 12]
+        state = want
+
+
+def test_gmm_advance_retires_degenerate_components(hh, orc, plan, env, pocs):
+    cfg = orc.config(plan, env, K=3)
+    lm = np.array(pocs.DEFAULTS["landmarks"], dtype=np.float64)
+    lx, ly = np.ascontiguousarray(lm[0]), np.ascontiguousarray(lm[1])
+    chain = orc.host_chain(cfg, 5)
+    state = orc.gmm_advance(cfg, orc.gmm_initial_state(cfg), None)
+    mom = orc.gmm_waypoint(cfg, 5, 0, state, 0, 300)
+    mom[1, :] = 0.0; mom[1, 1] = 100.0          # component 1: every sample collided
+    mom[2, 0] = 1.0                              # component 2: a single survivor
+    want = orc.gmm_advance(cfg, state, mom, chain["applied"][0], chain["Mdiag"][0], chain["z"][0])
+    nxt, par = np.zeros((3, 16)), np.zeros((3, 12))
+    hh.hh_gmm_advance(3, dp(state), dp(mom), dp(np.ascontiguousarray(chain["applied"][0])),
+                      dp(np.ascontiguousarray(chain["Mdiag"][0])), dp(np.ascontiguousarray(chain["z"][0])),
+                      8, dp(lx), dp(ly), C.c_double(pocs.DEFAULTS["Q"]), dp(nxt), dp(par))
+    assert np.array_equal(nxt[:, :14], want[:, :14])
+    assert list(want[:, 13]) == [1.0, 0.0, 0.0] and list(want[:, 12]) == [1.0, 0.0, 0.0]
+    assert list(par[:, 9]) == [2.0, 2.0, 2.0]   # only component 0 can be selected
+    # all dead: weights all zero (normalise divides by 1), nothing selectable but component 0
+    mom[0, :] = 0.0
+    want = orc.gmm_advance(cfg, state, mom, chain["applied"][0], chain["Mdiag"][0], chain["z"][0])
+    assert np.all(want[:, 12] == 0.0) and np.all(want[:, 13] == 0.0)
