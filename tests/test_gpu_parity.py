@@ -1,0 +1,278 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Integer work (collision flags, hit counters, survivor counts) must be
+bit-exact; floating-point sums are compared at a relative 1e-10 (the oracle adds in sample order,
+the GPU in a fixed tree); probabilities at 1e-9 -- well inside the 1e-6 absolute tolerance the
+north star states for the GMM path."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED0001
+REL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def ctx(pocs):
+    c = pocs.Context(0)
+    yield c
+    c.close()
+
+
+def close_moments(got, want):
+    assert np.array_equal(got[..., :2], want[..., :2]), "survivor / collision counts differ"
+    scale = np.maximum(np.abs(want[..., 2:]), 1.0)
+    assert np.max(np.abs(got[..., 2:] - want[..., 2:]) / scale) < REL
+
+
+def test_host_chain_is_bitwise_the_oracles(ctx, orc, plan, env):
+    cfg = orc.config(plan, env, K=3)
+    ctx.configure(plan, env, K=3, N=64, seed=SEED)
+    ctx.run_gmm_estimation()
+    got, want = ctx.host_chain(8), orc.host_chain(cfg, SEED)
+    for k in ("applied", "noisy", "z", "mu", "cov"):
+        assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("N", [1, 63, 257, 4096])
+def test_mc_hits_bit_exact(ctx, orc, plan, env, N):
+    cfg = orc.config(plan, env, K=3)
+    ctx.configure(plan, env, K=3, N=N, seed=SEED)
+    p = ctx.run_simulation()
+    n, hits, parts = orc.run_mc(cfg, SEED, N, want_particles=True)
+    xyz, got_hits = ctx.particles(N)
+    assert np.array_equal(got_hits, hits)                     # particlecollisions, u32 per particle
+    assert np.array_equal(xyz, parts)                         # final mcparticles, bit for bit
+    assert p == n / N
+
+
+def test_mc_fused_equals_streaming(ctx, pocs, plan, env):
+    ctx.configure(plan, env, K=3, N=5000, seed=7)
+    p1 = ctx.run_simulation()
+    x1, h1 = ctx.particles(5000)
+    ctx.set_option(pocs.OPT_MC_FUSED, 1)
+    ctx.set_seed(7)
+    p2 = ctx.run_simulation()
+    x2, h2 = ctx.particles(5000)
+    ctx.set_option(pocs.OPT_MC_FUSED, 0)
+    assert p1 == p2 and np.array_equal(h1, h2) and np.array_equal(x1, x2)
+
+
+def test_gmm_first_waypoint_samples_bit_exact(ctx, orc, plan, env):
+    """W = 1: the mixture is the initial one, so samples, flags and counts must match bit for bit."""
+    one = dict(traj=plan["traj"][:1], odom=plan["odom"][:0])
+    cfg = orc.config(one, env, K=3)
+    N = 5000
+    ctx.configure(one, env, K=3, N=N, seed=SEED)
+    p = ctx.run_gmm_estimation()
+    want = orc.run_gmm(cfg, SEED, N, want_samples=True)
+    xyz, flags = ctx.gmm_samples(N)
+    assert np.array_equal(flags, want["flags"])
+    assert np.array_equal(xyz, want["samples"])
+    close_moments(ctx.moments(0, 3), want["moments"][0])
+    assert abs(p - want["prob"]) < 1e-15
+
+
+@pytest.mark.parametrize("K,N", [(1, 3000), (3, 10000), (8, 6000), (3, 100)])
+def test_gmm_matches_oracle(ctx, orc, plan, env, K, N):
+    cfg = orc.config(plan, env, K=K)
+    ctx.configure(plan, env, K=K, N=N, seed=SEED + K)
+    p = ctx.run_gmm_estimation()
+    want = orc.run_gmm(cfg, SEED + K, N, want_samples=True)
+    W = cfg.W
+    got_m = np.array([ctx.moments(w, K) for w in range(W)])
+    close_moments(got_m, want["moments"])
+    assert np.max(np.abs(ctx.waypoint_probabilities() - want["probs"])) == 0.0   # counts / N
+    assert abs(p - want["prob"]) < 1e-12
+    for w in (0, 1, W // 2, W - 1):
+        m, c, wt = ctx.gmm_state(w, K)
+        assert np.allclose(m, want["states"][w][:, 0:3], rtol=1e-9, atol=1e-12)
+        assert np.allclose(c.reshape(K, 9), want["states"][w][:, 3:12], rtol=1e-7, atol=1e-14)
+        assert np.allclose(wt, want["states"][w][:, 12], rtol=1e-12, atol=0)
+    xyz, flags = ctx.gmm_samples(N)
+    assert np.array_equal(flags, want["flags"])
+    assert np.allclose(xyz, want["samples"], rtol=0, atol=1e-9)
+
+
+def test_gmm_one_million_samples_within_1e6(ctx, orc, plan, env):
+    """configs[1] of BASELINE.json at full size: bundled plan, 3 components, 10^6 samples."""
+    cfg = orc.config(plan, env, K=3)
+    N = 1000000
+    ctx.configure(plan, env, K=3, N=N, seed=SEED)
+    p = ctx.run_gmm_estimation()
+    want = orc.run_gmm(cfg, SEED, N)
+    assert abs(p - want["prob"]) <= 1e-6                       # the stated tolerance
+    assert np.max(np.abs(ctx.waypoint_probabilities() - want["probs"])) <= 1e-6
+    got_m = np.array([ctx.moments(w, 3) for w in range(cfg.W)])
+    assert np.array_equal(got_m[..., :2], want["moments"][..., :2])
+
+
+def test_gmm_variants_agree(ctx, pocs, plan, env):
+    """graph replay vs eager launches vs no sample store vs the per-waypoint step API."""
+    ctx.configure(plan, env, K=3, N=20000, seed=11)
+    base = ctx.run_gmm_estimation()
+    base_probs = ctx.waypoint_probabilities().copy()
+    base_m = ctx.moments(30, 3).copy()
+    for opt, val in ((pocs.OPT_USE_GRAPH, 0), (pocs.OPT_STORE_SAMPLES, 0), (pocs.OPT_PROFILE, 1)):
+        ctx.set_option(opt, val)
+        ctx.set_seed(11)
+        assert ctx.run_gmm_estimation() == base
+        assert np.array_equal(ctx.waypoint_probabilities(), base_probs)
+        assert np.array_equal(ctx.moments(30, 3), base_m)        # fixed-shape reduction: bitwise
+        ctx.set_option(opt, 1 - val)
+    ms, n = ctx.kernel_time()
+    assert n == 56 and ms > 0
+    ctx.set_seed(11)
+    again = ctx.run_gmm_estimation()                             # graph replayed a second time
+    assert again == base
+    ctx.set_seed(11)
+    ctx.gmm_begin()
+    for w in range(56):
+        ctx.gmm_step_local(w)
+    assert ctx.gmm_end() == base
+
+
+def test_runs_redraw_and_seed_rewinds(ctx, plan, env):
+    ctx.configure(plan, env, K=3, N=4000, seed=5)
+    a, b = ctx.run_gmm_estimation(), ctx.run_gmm_estimation()
+    assert a != b                                # a fresh stream per run, as the reference redraws
+    ctx.set_seed(5)
+    assert ctx.run_gmm_estimation() == a and ctx.run_gmm_estimation() == b
+
+
+def test_shards_partition_the_work(ctx, orc, plan, env):
+    """Two shards of one mixture waypoint add up to the whole (what the all-reduce relies on)."""
+    cfg = orc.config(plan, env, K=3)
+    N = 9001
+    ctx.configure(plan, env, K=3, N=N, seed=21)
+    ctx.run_gmm_estimation()
+    whole = ctx.moments(0, 3)
+    parts = []
+    for first, count in ((0, 4000), (4000, 5001)):
+        ctx.set_shard(first, count)
+        ctx.set_seed(21)
+        ctx.gmm_begin()
+        for w in range(56):
+            ctx.gmm_step_local(w)
+        ctx.gmm_end()
+        # without the exchange only waypoint 0 is meaningful: its moments are this shard's sums
+        parts.append(ctx.moments(0, 3).copy())
+        want = orc.gmm_waypoint(cfg, 21, 0, orc.gmm_advance(cfg, orc.gmm_initial_state(cfg), None), first, count)
+        close_moments(parts[-1], want)
+    ctx.set_shard(0, N)
+    assert np.array_equal((parts[0] + parts[1])[:, :2], whole[:, :2])
+    assert np.allclose(parts[0] + parts[1], whole, rtol=1e-12)
+    ctx.set_shard(0, 1000)
+    ctx.set_seed(21)
+    n0 = ctx.mc_run_local()
+    ctx.set_shard(1000, N - 1000)
+    ctx.set_seed(21)
+    n1 = ctx.mc_run_local()
+    ctx.set_shard(0, N)
+    ctx.set_seed(21)
+    assert n0 + n1 == ctx.mc_run_local() == orc.run_mc(cfg, 21, N)[0]
+
+
+def test_text_channel_is_a_drop_in(ctx, pocs, orc, plan, env):
+    """The exact command sequence of MCSimulation.py:154-207,238-245 over the text channel."""
+    def l2s(v):
+        return "".join(str(float(x)) + " " for x in v)       # list2String, MCSimulation.py:81-85
+    c = pocs.Context(0)
+    try:
+        c.set_env(env)
+        P = pocs.DEFAULTS
+        assert c.SendCommand("MyCommand [0.1,4.5,7.5,4.7]") == "output"
+        assert "runGMMEstimation" in c.SendCommand("help")
+        c.SendCommand("setAlphas " + l2s(P["alphas"]))
+        c.SendCommand("setQ " + str(P["Q"]))
+        c.SendCommand("setNumLandmarks 8")
+        c.SendCommand("setLandmarks " + l2s(P["landmarks"][0]) + l2s(P["landmarks"][1]))
+        c.SendCommand("setNumParticles 3000")
+        c.SendCommand("setInitialCovariance " + "".join(l2s(r) for r in P["cov0"]))
+        c.SendCommand("setPathLength 56")
+        t, o = plan["traj"].T, plan["odom"].T
+        c.SendCommand("setTrajectory " + "".join(repr(float(x)) + " " for r in t for x in r))
+        c.SendCommand("setOdometry " + "".join(repr(float(x)) + " " for r in o for x in r))
+        c.SendCommand("setNumGaussians 3")
+        c.SendCommand("setNumGMMSamples 3000")
+        c.SendCommand("setSeed 99")
+        p_gmm = float(c.SendCommand("runGMMEstimation"))
+        c.SendCommand("setSeed 99")
+        p_mc = float(c.SendCommand("runSimulation"))
+    finally:
+        c.close()
+    cfg = orc.config(plan, env, K=3)
+    assert abs(p_gmm - orc.run_gmm(cfg, 99, 3000)["prob"]) < 1e-12
+    assert p_mc == orc.run_mc(cfg, 99, 3000)[0] / 3000
+
+
+def test_error_behaviour(pocs, plan, env):
+    c = pocs.Context(0)
+    try:
+        with pytest.raises(pocs.PocsError) as e:
+            c.SendCommand("setLandmarks 1 2 3 4")
+        assert e.value.code == -2                                  # before setNumLandmarks
+        with pytest.raises(pocs.PocsError) as e:
+            c.SendCommand("setTrajectory 1 2 3")
+        assert e.value.code == -2                                  # before setPathLength
+        c.SendCommand("setPathLength 2")
+        with pytest.raises(pocs.PocsError) as e:
+            c.SendCommand("setTrajectory 1 2 3")
+        assert e.value.code == -1                                  # wrong token count
+        with pytest.raises(pocs.PocsError) as e:
+            c.SendCommand("setAlphas 1 2 3 4 5")
+        assert e.value.code == -1                                  # the reference overflows here
+        with pytest.raises(pocs.PocsError) as e:
+            c.SendCommand("runGMMEstimation")
+        assert e.value.code == -3                                  # incomplete configuration
+        with pytest.raises(pocs.PocsError) as e:
+            c.SendCommand("noSuchCommand 1")
+        assert e.value.code == -5
+        with pytest.raises(pocs.PocsError) as e:
+            c.SendCommand("setNumGaussians 9")
+        assert e.value.code == -1
+        with pytest.raises(pocs.PocsError) as e:
+            c.SendCommand("setQ abc")
+        assert e.value.code == -1
+        assert c.SendCommand("ArmaCommand") == ""
+    finally:
+        c.close()
+
+
+def test_rotated_obstacles_and_offset_footprint(ctx, orc, plan):
+    """pr2custom.env.xml has boxes rotated by +-60 / 90 degrees: the primitive is a general OBB."""
+    env2 = dict(footprint=[0.05, -0.02, 0.30, 0.25],
+                boxes=np.array([[0.9, 1.0, 0.1, 0.6, math.radians(60)], [-2.0, -0.9, 0.5, 0.1, math.radians(-60)],
+                                [1.8, -0.3, 0.2, 0.7, math.radians(90)], [0.0, 1.9, 4.0, 0.1, 0.0]]))
+    cfg = orc.config(plan, env2, K=2)
+    ctx.configure(plan, env2, K=2, N=6000, seed=3)
+    p = ctx.run_gmm_estimation()
+    want = orc.run_gmm(cfg, 3, 6000, want_samples=True)
+    assert np.array_equal(ctx.gmm_samples(6000)[1], want["flags"])
+    assert abs(p - want["prob"]) < 1e-12
+    ctx.set_seed(3)
+    assert ctx.run_simulation() == orc.run_mc(cfg, 3, 6000)[0] / 6000
+
+
+def test_full_size_properties(ctx, pocs, plan, env):
+    """BASELINE.json configs[2] at full size (500 waypoints, 10^7 samples, 8 components): the oracle
+    would need ~25 min, so check size-independent properties instead."""
+    big = pocs.resample_plan(plan, 500)
+    N, K = 10_000_000, 8
+    ctx.configure(big, env, K=K, N=N, seed=SEED)
+    p1 = ctx.run_gmm_estimation()
+    probs = ctx.waypoint_probabilities().copy()
+    for w in (0, 17, 250, 499):
+        m = ctx.moments(w, K)
+        assert m[:, 0].sum() + m[:, 1].sum() == N            # every sample counted exactly once
+        assert abs(m[:, 1].sum() / N - probs[w]) == 0.0
+        _, covs, wts = ctx.gmm_state(w, K)
+        assert abs(wts.sum() - 1.0) < 1e-12
+        for k in range(K):
+            assert np.all(np.linalg.eigvalsh((covs[k] + covs[k].T) / 2) > 0)
+    assert abs(p1 - (1.0 - np.prod(1.0 - probs))) < 1e-12      # F1: 1 - prod(1 - p_i)
+    ctx.set_seed(SEED)
+    assert ctx.run_gmm_estimation() == p1                       # bitwise reproducible
+    assert 0.0 < p1 <= 1.0
