@@ -77,7 +77,7 @@ int pocs_set_option(pocs_ctx* ctx, int option, long long value);
 /* ---- sharding over GPUs (one process per GPU; the caller owns the collective) -----------
  * A context evaluates global sample / particle indices [first, first+count) of the N configured;
  * random draws are keyed by the GLOBAL index so results do not depend on the partition. */
-int pocs_set_shard(pocs_ctx* ctx, long long first, long long count);
+int pocs_set_shard(pocs_ctx* ctx, long long first, long long count);   /* (-1, -1) = the whole range again */
 int pocs_set_stream(pocs_ctx* ctx, void* hip_stream);                 /* launch on this stream (e.g. torch's current stream) */
 
 /* GMM, one waypoint at a time: begin -> for w in 0..W-1 { step_local(w); <all-reduce SUM of
@@ -96,7 +96,7 @@ int pocs_mc_run_local(pocs_ctx* ctx, unsigned long long* collided);
 int pocs_get_path_length(const pocs_ctx* ctx);
 int pocs_get_waypoint_probabilities(pocs_ctx* ctx, double* out, int cap);         /* `probabilities`, MCSimulator.h:660,678,817 */
 int pocs_get_moments(pocs_ctx* ctx, int waypoint, double* out, int cap);          /* K x 11: nFree nColl Sx Sy St Sxx Sxy Sxt Syy Syt Stt */
-int pocs_get_gmm_state(pocs_ctx* ctx, int waypoint, double* means3, double* covs9, double* weights);  /* the mixture sampled at `waypoint` */
+int pocs_get_gmm_state(pocs_ctx* ctx, int waypoint, double* means3, double* covs9, double* weights, double* alive);  /* the mixture sampled at `waypoint`; alive[k] = 0 for a retired component */
 int pocs_get_host_chain(pocs_ctx* ctx, double* applied3, double* noisy3, double* z, double* mu3, double* cov9); /* per step i<W-1; z is L per step */
 long long pocs_copy_gmm_samples(pocs_ctx* ctx, double* xyt_aos, int16_t* flags, long long cap);  /* last waypoint's shard, 3 x n column-major like arma (x,y,theta triples) */
 long long pocs_copy_particles(pocs_ctx* ctx, double* xyt_aos, uint32_t* hits, long long cap);   /* mcparticles / particlecollisions, MCSimulator.h:105,108 */

@@ -55,7 +55,7 @@ SIGNATURES = {
     "pocs_get_path_length": (C.c_int, [_vp]),
     "pocs_get_waypoint_probabilities": (C.c_int, [_vp, _dp, C.c_int]),
     "pocs_get_moments": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
-    "pocs_get_gmm_state": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
+    "pocs_get_gmm_state": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "pocs_get_host_chain": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
     "pocs_copy_gmm_samples": (C.c_longlong, [_vp, _dp, C.POINTER(C.c_int16), C.c_longlong]),
     "pocs_copy_particles": (C.c_longlong, [_vp, _dp, C.POINTER(C.c_uint32), C.c_longlong]),
@@ -184,7 +184,8 @@ class Context:
     def set_option(self, opt, val):
         self._chk(self.lib.pocs_set_option(self.h, opt, val))
 
-    def set_shard(self, first, count):
+    def set_shard(self, first=-1, count=-1):
+        """Evaluate global indices [first, first+count); no arguments = the whole range."""
         self._chk(self.lib.pocs_set_shard(self.h, first, count))
 
     def set_stream(self, stream_ptr):
@@ -260,10 +261,17 @@ class Context:
         return out.reshape(K, NMOM)
 
     def gmm_state(self, w, K):
-        m, c, wt = np.zeros((K, 3)), np.zeros((K, 9)), np.zeros(K)
+        m, c, wt, al = np.zeros((K, 3)), np.zeros((K, 9)), np.zeros(K), np.zeros(K)
         self._chk(self.lib.pocs_get_gmm_state(self.h, w, m.ctypes.data_as(_dp), c.ctypes.data_as(_dp),
-                                              wt.ctypes.data_as(_dp)))
-        return m, c.reshape(K, 3, 3), wt
+                                              wt.ctypes.data_as(_dp), al.ctypes.data_as(_dp)))
+        return m, c.reshape(K, 3, 3), wt, al
+
+    def gmm_state_raw(self, w, K):
+        """K x 16 rows [mean(3) cov(9) weight alive 0 0] -- the layout the oracle uses too."""
+        m, c, wt, al = self.gmm_state(w, K)
+        s = np.zeros((K, 16))
+        s[:, 0:3], s[:, 3:12], s[:, 12], s[:, 13] = m, c.reshape(K, 9), wt, al
+        return s
 
     def host_chain(self, L):
         n = max(self.path_length() - 1, 0)

@@ -801,6 +801,7 @@ int pocs_set_option(pocs_ctx* c, int option, long long value) {
 int pocs_set_shard(pocs_ctx* c, long long first, long long count) {
   if (c) c->epoch++;
   if (!c) return POCS_E_ARG;
+  if (first == -1 && count == -1) { c->shard_first = -1; c->shard_count = -1; return POCS_OK; }   // whole range
   if (first < 0 || count < 0) return fail(c, POCS_E_ARG, "negative shard");
   c->shard_first = first; c->shard_count = count;
   return POCS_OK;
@@ -914,7 +915,7 @@ int pocs_get_moments(pocs_ctx* c, int w, double* out, int cap) {
   return n;
 }
 
-int pocs_get_gmm_state(pocs_ctx* c, int w, double* means3, double* covs9, double* weights) {
+int pocs_get_gmm_state(pocs_ctx* c, int w, double* means3, double* covs9, double* weights, double* alive) {
   if (!c) return POCS_E_ARG;
   if (w < 0 || w > c->last_gmm_wp || !c->d_state.p) return fail(c, POCS_E_ARG, "no mixture for waypoint %d", w);
   HIPCHK(c, hipSetDevice(c->device));
@@ -925,6 +926,7 @@ int pocs_get_gmm_state(pocs_ctx* c, int w, double* means3, double* covs9, double
     if (means3) memcpy(means3 + 3 * k, &s[(size_t)k * POCS_STATE_STRIDE], 3 * sizeof(double));
     if (covs9) memcpy(covs9 + 9 * k, &s[(size_t)k * POCS_STATE_STRIDE + 3], 9 * sizeof(double));
     if (weights) weights[k] = s[(size_t)k * POCS_STATE_STRIDE + 12];
+    if (alive) alive[k] = s[(size_t)k * POCS_STATE_STRIDE + 13];
   }
   return c->K;
 }

@@ -78,22 +78,39 @@ def test_gmm_first_waypoint_samples_bit_exact(ctx, orc, plan, env):
 @pytest.mark.parametrize("K,N", [(1, 3000), (3, 10000), (8, 6000), (3, 100)])
 def test_gmm_matches_oracle(ctx, orc, plan, env, K, N):
     cfg = orc.config(plan, env, K=K)
-    ctx.configure(plan, env, K=K, N=N, seed=SEED + K)
+    seed = SEED + K
+    ctx.configure(plan, env, K=K, N=N, seed=seed)
     p = ctx.run_gmm_estimation()
-    want = orc.run_gmm(cfg, SEED + K, N, want_samples=True)
     W = cfg.W
     got_m = np.array([ctx.moments(w, K) for w in range(W)])
-    close_moments(got_m, want["moments"])
-    assert np.max(np.abs(ctx.waypoint_probabilities() - want["probs"])) == 0.0   # counts / N
+    got_s = np.array([ctx.gmm_state_raw(w, K) for w in range(W)])
+    chain = orc.host_chain(cfg, seed)
+
+    # (1) stage by stage, the oracle fed with the GPU's own inputs: every stage must agree to the
+    #     last bit, except the order in which the moment sums are added
+    st0 = orc.gmm_advance(cfg, orc.gmm_initial_state(cfg), None)
+    assert np.array_equal(got_s[0][:, :14], st0[:, :14])
+    for w in range(W):
+        mom, samples, flags, comp = orc.gmm_waypoint(cfg, seed, w, got_s[w], 0, N, want_samples=True)
+        assert np.array_equal(got_m[w][:, :2], mom[:, :2]), w              # survivors / collisions
+        scale = np.maximum(np.abs(mom[:, 2:]), mom[:, :1] * 1e-3 + 1e-300)
+        assert np.max(np.abs(got_m[w][:, 2:] - mom[:, 2:]) / scale) < 1e-11, w
+        if w + 1 < W:                                                      # device EKF / truncation / Cholesky
+            nxt = orc.gmm_advance(cfg, got_s[w], got_m[w], chain["applied"][w], chain["Mdiag"][w], chain["z"][w])
+            assert np.array_equal(got_s[w + 1][:, :14], nxt[:, :14]), w
+    xyz, gflags = ctx.gmm_samples(N)                                       # last waypoint, as stored in HBM
+    assert np.array_equal(gflags, flags) and np.array_equal(xyz, samples)
+
+    # (2) free running: both sides from the seed alone.  The single-pass covariance of the
+    #     reference (op_cov) cancels ~4 digits, so summation order shows up at 1e-11 in the state
+    #     and is carried along the 56 steps; flags, hence probabilities, still agree exactly here.
+    want = orc.run_gmm(cfg, seed, N)
+    assert np.array_equal(got_m[..., :2], want["moments"][..., :2])
+    assert np.array_equal(ctx.waypoint_probabilities(), want["probs"])
     assert abs(p - want["prob"]) < 1e-12
-    for w in (0, 1, W // 2, W - 1):
-        m, c, wt = ctx.gmm_state(w, K)
-        assert np.allclose(m, want["states"][w][:, 0:3], rtol=1e-9, atol=1e-12)
-        assert np.allclose(c.reshape(K, 9), want["states"][w][:, 3:12], rtol=1e-7, atol=1e-14)
-        assert np.allclose(wt, want["states"][w][:, 12], rtol=1e-12, atol=0)
-    xyz, flags = ctx.gmm_samples(N)
-    assert np.array_equal(flags, want["flags"])
-    assert np.allclose(xyz, want["samples"], rtol=0, atol=1e-9)
+    assert np.allclose(got_s[..., 0:3], want["states"][..., 0:3], rtol=0, atol=1e-8)
+    assert np.allclose(got_s[..., 3:12], want["states"][..., 3:12], rtol=1e-5, atol=1e-12)
+    assert np.allclose(got_s[..., 12], want["states"][..., 12], rtol=1e-12, atol=0)
 
 
 def test_gmm_one_million_samples_within_1e6(ctx, orc, plan, env):
@@ -161,7 +178,7 @@ def test_shards_partition_the_work(ctx, orc, plan, env):
         parts.append(ctx.moments(0, 3).copy())
         want = orc.gmm_waypoint(cfg, 21, 0, orc.gmm_advance(cfg, orc.gmm_initial_state(cfg), None), first, count)
         close_moments(parts[-1], want)
-    ctx.set_shard(0, N)
+    ctx.set_shard()
     assert np.array_equal((parts[0] + parts[1])[:, :2], whole[:, :2])
     assert np.allclose(parts[0] + parts[1], whole, rtol=1e-12)
     ctx.set_shard(0, 1000)
@@ -170,7 +187,7 @@ def test_shards_partition_the_work(ctx, orc, plan, env):
     ctx.set_shard(1000, N - 1000)
     ctx.set_seed(21)
     n1 = ctx.mc_run_local()
-    ctx.set_shard(0, N)
+    ctx.set_shard()
     ctx.set_seed(21)
     assert n0 + n1 == ctx.mc_run_local() == orc.run_mc(cfg, 21, N)[0]
 
@@ -268,7 +285,7 @@ def test_full_size_properties(ctx, pocs, plan, env):
         m = ctx.moments(w, K)
         assert m[:, 0].sum() + m[:, 1].sum() == N            # every sample counted exactly once
         assert abs(m[:, 1].sum() / N - probs[w]) == 0.0
-        _, covs, wts = ctx.gmm_state(w, K)
+        _, covs, wts, _ = ctx.gmm_state(w, K)
         assert abs(wts.sum() - 1.0) < 1e-12
         for k in range(K):
             assert np.all(np.linalg.eigvalsh((covs[k] + covs[k].T) / 2) > 0)
