@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--samples", type=int, default=0, help="override samples per GPU (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=float, default=6.0e7, help="size of the CPU baseline sample")
     args = ap.parse_args()
@@ -78,6 +79,8 @@ def main():
         torch.cuda.set_device(local)
 
     W, n_local, K, path = WORKLOADS[args.workload]
+    if args.samples:
+        n_local = args.samples
     plan = pocs_amd.load_plan()
     if W != 56:
         plan = pocs_amd.resample_plan(plan, W)

@@ -123,9 +123,17 @@ void drop_graphs(pocs_ctx* c) {
 }
 
 int grid_for(long long count) {
-  // ~8 evaluations per thread, capped (grid-stride beyond that); >= 1 block
-  long long nb = (count + (long long)POCS_BLOCK * 8 - 1) / ((long long)POCS_BLOCK * 8);
+  // One block per 256 evaluations up to `bpc` resident blocks per CU (256 CUs), grid-stride
+  // beyond that.  POCS_BLOCKS_PER_CU overrides the default for tuning sweeps.
+  static int bpc = 0;
+  if (bpc == 0) {
+    const char* e = getenv("POCS_BLOCKS_PER_CU");
+    bpc = e ? atoi(e) : 3;
+    if (bpc < 1 || bpc > 8) bpc = 3;
+  }
+  long long nb = (count + POCS_BLOCK - 1) / POCS_BLOCK;
   if (nb < 1) nb = 1;
+  if (nb > 256LL * bpc) nb = 256LL * bpc;
   if (nb > POCS_MAX_BLOCKS) nb = POCS_MAX_BLOCKS;
   return (int)nb;
 }

@@ -26,15 +26,34 @@
 
 namespace {
 
+// Wave64 sums without LDS traffic: four DPP steps leave every lane of a 16-lane row holding its
+// row's sum (pairs, quads, half rows, rows), then the four row sums are read back through SGPRs
+// and added in row order.  The shape is fixed, so a sum is bitwise reproducible run to run.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double lane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                          __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);   // row_half_mirror
+  v += dpp_f64<0x140>(v);   // row_mirror
+  return ((lane_f64(v, 0) + lane_f64(v, 16)) + lane_f64(v, 32)) + lane_f64(v, 48);
 }
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16) +
+         (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 // Stage the collision world into LDS.  s_obs must hold POCS_MAX_OBSTACLES*POCS_OBS_STRIDE doubles.
@@ -91,23 +110,25 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_gmm_sample(pocs_gmm_launch a) {
       a.x[i] = x; a.y[i] = y; a.th[i] = t;
       a.flags[i] = hit ? (int16_t)1 : (int16_t)0;
     }
-    const double fx = hit ? 0.0 : x, fy = hit ? 0.0 : y, ft = hit ? 0.0 : t;
-    const double m0 = fx, m1 = fy, m2 = ft;
-    const double m3 = fx * fx, m4 = fx * fy, m5 = fx * ft, m6 = fy * fy, m7 = fy * ft, m8 = ft * ft;
+    // T1 sums: acc_k += ind_k * (x, y, t, xx, xy, xt, yy, yt, tt) with ind_k = 1.0 for the
+    // sample's own component when it is collision free, else 0.0; fma(1, v, acc) == acc + v and
+    // fma(0, v, acc) == acc exactly, so this is the masked sum without the select instructions.
+    const double xx = x * x, xy = x * y, xt = x * t, yy = y * y, yt = y * t, tt = t * t;
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) {
       const bool sel = (k == kk);
       nfree[kk] += (sel && !hit) ? 1u : 0u;
       ncoll[kk] += (sel && hit) ? 1u : 0u;
-      acc[kk][0] += sel ? m0 : 0.0;
-      acc[kk][1] += sel ? m1 : 0.0;
-      acc[kk][2] += sel ? m2 : 0.0;
-      acc[kk][3] += sel ? m3 : 0.0;
-      acc[kk][4] += sel ? m4 : 0.0;
-      acc[kk][5] += sel ? m5 : 0.0;
-      acc[kk][6] += sel ? m6 : 0.0;
-      acc[kk][7] += sel ? m7 : 0.0;
-      acc[kk][8] += sel ? m8 : 0.0;
+      const double ind = (sel && !hit) ? 1.0 : 0.0;
+      acc[kk][0] = fma(ind, x, acc[kk][0]);
+      acc[kk][1] = fma(ind, y, acc[kk][1]);
+      acc[kk][2] = fma(ind, t, acc[kk][2]);
+      acc[kk][3] = fma(ind, xx, acc[kk][3]);
+      acc[kk][4] = fma(ind, xy, acc[kk][4]);
+      acc[kk][5] = fma(ind, xt, acc[kk][5]);
+      acc[kk][6] = fma(ind, yy, acc[kk][6]);
+      acc[kk][7] = fma(ind, yt, acc[kk][7]);
+      acc[kk][8] = fma(ind, tt, acc[kk][8]);
     }
   }
 
