@@ -1,0 +1,80 @@
+"""Sharding of the two estimators over GPUs: one process per GPU, torch.distributed (RCCL).
+
+The exchange protocol lives here, independent of what evaluates a shard, so that it is the same
+code on 8 MI355X (engine = GpuEngine over libpocs.so) and in the CPU tests (world size 2, gloo,
+an oracle-backed engine standing in for the kernels):
+
+  MC   no data-path collective; ONE all_reduce(SUM) of the integer hit count at the end.
+  GMM  one all_reduce(SUM) of the 11*K moment doubles per waypoint (MCSimulator.h:592-629 needs
+       the global truncated moments before the next waypoint's mixture exists).
+
+Random draws are keyed by the GLOBAL sample index, so the result does not depend on the split.
+"""
+import numpy as np
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous, balanced split of range(n_total): returns (first, count) of `rank`."""
+    base, rem = divmod(int(n_total), int(world))
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def combine_probabilities(colliding_per_waypoint, n_total):
+    """p_w = colliding / N (MCSimulator.h:633-641); result = 1 - prod(1 - p_w) (:848-856)."""
+    probs = np.asarray(colliding_per_waypoint, dtype=np.float64) / float(n_total)
+    prod = 1.0
+    for p in probs:
+        prod *= (1.0 - p)
+    return 1.0 - prod, probs
+
+
+def run_gmm_sharded(engine, dist=None):
+    """engine: begin(), step_local(w), moments(w) -> tensor view [11*K] (device of the engine),
+    end() -> probability, attributes W.  dist: torch.distributed (initialised) or None."""
+    engine.begin()
+    for w in range(engine.W):
+        engine.step_local(w)
+        if dist is not None and dist.get_world_size() > 1:
+            dist.all_reduce(engine.moments(w))
+    return engine.end()
+
+
+def run_mc_sharded(engine, n_total, dist=None):
+    """engine: mc_local() -> tensor [1] int64 with the shard's collided count."""
+    cnt = engine.mc_local()
+    if dist is not None and dist.get_world_size() > 1:
+        dist.all_reduce(cnt)
+    return int(cnt.item()) / float(n_total)
+
+
+class GpuEngine:
+    """A libpocs context bound to this rank's GPU, torch's current stream and a torch-owned
+    moments buffer (so all_reduce can take views of it)."""
+
+    def __init__(self, ctx, W, K, n_total, rank=0, world=1, per_rank=None):
+        import torch
+        self.ctx, self.W, self.K, self.torch = ctx, W, K, torch
+        first, count = (rank * per_rank, per_rank) if per_rank else shard_range(n_total, rank, world)
+        ctx.set_shard(first, count)
+        self.count = count
+        if world > 1:
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.buf = torch.zeros(W * K * 11, dtype=torch.float64, device="cuda")
+        ctx.gmm_bind_moments(self.buf.data_ptr(), self.buf.numel())
+
+    def begin(self):
+        self.ctx.gmm_begin()
+
+    def step_local(self, w):
+        self.ctx.gmm_step_local(w)
+
+    def moments(self, w):
+        n = self.K * 11
+        return self.buf[w * n:(w + 1) * n]
+
+    def end(self):
+        return self.ctx.gmm_end()
+
+    def mc_local(self):
+        return self.torch.tensor([self.ctx.mc_run_local()], dtype=self.torch.int64, device="cuda")
