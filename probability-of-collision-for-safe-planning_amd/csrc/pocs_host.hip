@@ -62,7 +62,7 @@ struct pocs_ctx {
 
   // ---- device state ----
   DevBuf d_env, d_sensor, d_hdr, d_chain, d_state, d_param, d_moments, d_partial;
-  DevBuf d_sx, d_sy, d_st, d_flags, d_px, d_py, d_pt, d_hits, d_total;
+  DevBuf d_sx, d_sy, d_st, d_flags, d_px, d_py, d_pt, d_hits, d_total, d_ticket;
   double* ext_moments = nullptr;         // caller-owned moments buffer (multi-GPU), or null
   long long ext_moments_len = 0;
   void* h_pin = nullptr;                 // pinned staging: hdr | chain | state0 | moments | total
@@ -122,21 +122,24 @@ void drop_graphs(pocs_ctx* c) {
   c->graph_mc_key.clear();
 }
 
-int grid_for(long long count) {
-  // One block per 256 evaluations up to `bpc` resident blocks per CU (256 CUs), grid-stride
+int grid_blocks(long long count, int block, int default_bpc) {
+  // One block per `block` evaluations up to `bpc` resident blocks per CU (256 CUs), grid-stride
   // beyond that.  POCS_BLOCKS_PER_CU overrides the default for tuning sweeps.
-  static int bpc = 0;
-  if (bpc == 0) {
+  static int env_bpc = -1;
+  if (env_bpc < 0) {
     const char* e = getenv("POCS_BLOCKS_PER_CU");
-    bpc = e ? atoi(e) : 3;
-    if (bpc < 1 || bpc > 8) bpc = 3;
+    env_bpc = e ? atoi(e) : 0;
+    if (env_bpc < 0 || env_bpc > 8) env_bpc = 0;
   }
-  long long nb = (count + POCS_BLOCK - 1) / POCS_BLOCK;
+  const int bpc = env_bpc ? env_bpc : default_bpc;
+  long long nb = (count + block - 1) / block;
   if (nb < 1) nb = 1;
   if (nb > 256LL * bpc) nb = 256LL * bpc;
   if (nb > POCS_MAX_BLOCKS) nb = POCS_MAX_BLOCKS;
   return (int)nb;
 }
+int grid_for(long long count) { return grid_blocks(count, POCS_GMM_BLOCK, 1); }      // k_gmm_step
+int grid_for_mc(long long count) { return grid_blocks(count, POCS_BLOCK, 3); }       // MC kernels
 
 // ---------------------------------------------------------------------------------------------
 // Host chain: everything in EKF_GaussProp's loop body that does not touch particles/samples
@@ -331,6 +334,7 @@ int gmm_prepare(pocs_ctx* c) {
   if (c->ext_moments && c->ext_moments_len < (long long)(W * K * POCS_NMOM))
     return fail(c, POCS_E_BUFFER, "bound moments buffer too small");
   if (int r = ensure(c, c->d_partial, (size_t)nblk * K * POCS_NMOM * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_ticket, W * sizeof(unsigned))) return r;
   if (c->opt_store) {
     const size_t n = (size_t)(count > 0 ? count : 1);
     if (int r = ensure(c, c->d_sx, n * sizeof(double))) return r;
@@ -365,39 +369,57 @@ int gmm_upload_run(pocs_ctx* c, uint64_t seed) {
   return POCS_OK;
 }
 
-int enqueue_finalize(pocs_ctx* c, int nblk, int reduce_wp, int advance_wp) {
-  pocs_finalize_launch f;
-  f.partial = (const double*)c->d_partial.p; f.nblk = nblk;
-  f.moments = moments_dev(c);
-  f.state = (double*)c->d_state.p; f.param = (double*)c->d_param.p;
-  f.chain = (const double*)c->d_chain.p; f.sensor = (const pocs_sensor*)c->d_sensor.p;
-  f.K = c->K; f.reduce_wp = reduce_wp; f.advance_wp = advance_wp;
-  HIPCHK(c, pocs_launch_gmm_finalize(f, c->stream));
+// One waypoint = one launch of k_gmm_step: its head folds moments[w-1] (already reduced, by the
+// previous launch's last block and -- across GPUs -- by the caller's all-reduce) into the mixture.
+void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long count, int w) {
+  memset(a, 0, sizeof *a);
+  a->hdr = (const pocs_run_header*)c->d_hdr.p;
+  a->env = (const pocs_env_dev*)c->d_env.p;
+  a->chain = (const double*)c->d_chain.p;
+  a->sensor = (const pocs_sensor*)c->d_sensor.p;
+  a->state = (double*)c->d_state.p;
+  a->param = (double*)c->d_param.p;
+  a->moments = moments_dev(c);
+  a->partial = (double*)c->d_partial.p;
+  a->ticket = (unsigned*)c->d_ticket.p;
+  a->x = (double*)c->d_sx.p; a->y = (double*)c->d_sy.p; a->th = (double*)c->d_st.p;
+  a->flags = (int16_t*)c->d_flags.p;
+  a->first = first; a->count = count;
+  a->fp = c->fp; a->M = (int)(c->boxes.size() / 5);
+  a->waypoint = w; a->store = c->opt_store ? 1 : 0;
+}
+
+// state/param[w] from state/moments[w-1]: its own tiny launch for waypoint 0 and, when sharded,
+// after the caller's all-reduce; on one GPU the last block of k_gmm_step(w-1) has done it already.
+int enqueue_advance(pocs_ctx* c, int w) {
+  pocs_gmm_launch a;
+  fill_gmm_launch(c, &a, 0, 0, w);
+  HIPCHK(c, pocs_launch_gmm_advance(c->K, a, c->stream));
   return POCS_OK;
 }
 
-int enqueue_sample(pocs_ctx* c, int nblk, long long first, long long count, int w, int prof_slot) {
+int enqueue_step(pocs_ctx* c, int nblk, long long first, long long count, int w, bool advance_in_tail,
+                 int prof_slot) {
   pocs_gmm_launch a;
-  a.hdr = (const pocs_run_header*)c->d_hdr.p;
-  a.env = (const pocs_env_dev*)c->d_env.p;
-  a.param = (const double*)c->d_param.p + (size_t)w * c->K * POCS_PARAM_STRIDE;
-  a.x = (double*)c->d_sx.p; a.y = (double*)c->d_sy.p; a.th = (double*)c->d_st.p;
-  a.flags = (int16_t*)c->d_flags.p;
-  a.partial = (double*)c->d_partial.p;
-  a.first = first; a.count = count; a.waypoint = w; a.store = c->opt_store ? 1 : 0;
+  fill_gmm_launch(c, &a, first, count, w);
+  a.advance_in_tail = (advance_in_tail && w + 1 < c->W) ? 1 : 0;
   if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot], c->stream));
-  HIPCHK(c, pocs_launch_gmm_sample(c->K, nblk, a, c->stream));
+  HIPCHK(c, pocs_launch_gmm_step(c->K, nblk, a, c->stream));
   if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot + 1], c->stream));
+  return POCS_OK;
+}
+
+int enqueue_ticket_reset(pocs_ctx* c) {
+  HIPCHK(c, hipMemsetAsync(c->d_ticket.p, 0, (size_t)c->W * sizeof(unsigned), c->stream));
   return POCS_OK;
 }
 
 int enqueue_gmm_all(pocs_ctx* c, long long first, long long count, bool prof) {
   const int W = c->W, nblk = grid_for(count);
-  for (int w = 0; w < W; ++w) {
-    if (int r = enqueue_finalize(c, nblk, w - 1, w)) return r;
-    if (int r = enqueue_sample(c, nblk, first, count, w, prof ? w : -1)) return r;
-  }
-  if (int r = enqueue_finalize(c, nblk, W - 1, -1)) return r;
+  if (int r = enqueue_ticket_reset(c)) return r;
+  if (int r = enqueue_advance(c, 0)) return r;
+  for (int w = 0; w < W; ++w)
+    if (int r = enqueue_step(c, nblk, first, count, w, true, prof ? w : -1)) return r;
   const PinLayout pl = pin_layout(c);
   HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.moments, moments_dev(c),
                            (size_t)W * c->K * POCS_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -477,7 +499,7 @@ int mc_shard(pocs_ctx* c, long long* first, long long* count) {
 }
 
 int enqueue_mc_all(pocs_ctx* c, long long first, long long count, bool prof) {
-  const int W = c->W, nblk = grid_for(count);
+  const int W = c->W, nblk = grid_for_mc(count);
   pocs_mc_launch a;
   a.hdr = (const pocs_run_header*)c->d_hdr.p;
   a.env = (const pocs_env_dev*)c->d_env.p;
@@ -657,7 +679,7 @@ void pocs_destroy(pocs_ctx* c) {
     for (hipEvent_t e : c->events) hipEventDestroy(e);
     DevBuf* all[] = {&c->d_env, &c->d_sensor, &c->d_hdr, &c->d_chain, &c->d_state, &c->d_param,
                      &c->d_moments, &c->d_partial, &c->d_sx, &c->d_sy, &c->d_st, &c->d_flags,
-                     &c->d_px, &c->d_py, &c->d_pt, &c->d_hits, &c->d_total};
+                     &c->d_px, &c->d_py, &c->d_pt, &c->d_hits, &c->d_total, &c->d_ticket};
     for (DevBuf* b : all) if (b->p) hipFree(b->p);
     if (c->h_pin) hipHostFree(c->h_pin);
     hipStreamDestroy(c->own_stream);
@@ -862,6 +884,7 @@ int pocs_gmm_begin(pocs_ctx* c) {
   c->run_index++;
   if (int r = gmm_upload_run(c, seed)) return r;
   if (int r = prof_begin(c, (size_t)c->W)) return r;
+  if (int r = enqueue_ticket_reset(c)) return r;
   c->gmm_open = true;
   c->last_gmm_wp = -1;
   return POCS_OK;
@@ -873,10 +896,8 @@ int pocs_gmm_step_local(pocs_ctx* c, int w) {
   if (w != c->last_gmm_wp + 1 || w >= c->W) return fail(c, POCS_E_ORDER, "waypoint %d out of sequence", w);
   long long first, count;
   if (int r = gmm_shard(c, &first, &count)) return r;
-  const int nblk = grid_for(count);
-  if (int r = enqueue_finalize(c, nblk, -1, w)) return r;
-  if (int r = enqueue_sample(c, nblk, first, count, w, c->opt_profile ? w : -1)) return r;
-  if (int r = enqueue_finalize(c, nblk, w, -1)) return r;
+  if (int r = enqueue_advance(c, w)) return r;        // folds the (reduced) moments of w-1
+  if (int r = enqueue_step(c, grid_for(count), first, count, w, false, c->opt_profile ? w : -1)) return r;
   c->last_gmm_wp = w;
   c->last_gmm_count = count;
   return POCS_OK;

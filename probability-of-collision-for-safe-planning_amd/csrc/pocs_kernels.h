@@ -6,7 +6,8 @@
 #include "pocs_collide.h"
 #include "pocs_model.h"
 
-#define POCS_BLOCK 256
+#define POCS_BLOCK 256        // MC kernels
+#define POCS_GMM_BLOCK 512    // k_gmm_step: 8 waves, one block per CU -> 256 partial rows
 #define POCS_MAX_BLOCKS 2048
 // chain record (doubles), one per step i < W-1:
 //   [0..2] applied control   [3..5] diag of M   [6..8] the noisy control actually driven (MC)
@@ -29,27 +30,23 @@ struct pocs_run_header {         // per-run scalars read by every kernel (so a c
 
 struct pocs_gmm_launch {
   const pocs_run_header* hdr;
-  const pocs_env_dev* env;
-  const double* param;           // K x POCS_PARAM_STRIDE for this waypoint
-  double* x; double* y; double* th;   // SoA sample buffers of this shard (may be null when !store)
+  const pocs_env_dev* env;       // obstacle table (records only; M and the footprint travel below)
+  const double* chain;           // [W-1][POCS_CHAIN_STRIDE]
+  const pocs_sensor* sensor;
+  double* state;                 // [W][K*POCS_STATE_STRIDE]  mixture sampled at each waypoint
+  double* param;                 // [W][K*POCS_PARAM_STRIDE]  its sampler parameters (audit copy)
+  double* moments;               // [W][K*POCS_NMOM]          reduced moments of each waypoint
+  double* partial;               // [gridDim.x][K*POCS_NMOM]  block partials of this launch
+  unsigned* ticket;              // [W] arrival counters, zeroed once per run
+  double* x; double* y; double* th;   // SoA sample buffers of this shard (unused when !store)
   int16_t* flags;
-  double* partial;               // gridDim.x x (K*POCS_NMOM)
   long long first;               // global index of the shard's first sample
   long long count;               // samples in this shard
+  pocs_footprint fp;
+  int M;
   int waypoint;
   int store;
-};
-
-struct pocs_finalize_launch {
-  const double* partial; int nblk;     // block partials of waypoint `reduce_wp`
-  double* moments;                     // [W][K*POCS_NMOM]
-  double* state;                       // [W][K*POCS_STATE_STRIDE]
-  double* param;                       // [W][K*POCS_PARAM_STRIDE]
-  const double* chain;                 // [W-1][POCS_CHAIN_STRIDE]
-  const pocs_sensor* sensor;
-  int K;
-  int reduce_wp;                       // >= 0: fold partials into moments[reduce_wp]
-  int advance_wp;                      // >= 0: build state/param[advance_wp] from state/moments[advance_wp-1]
+  int advance_in_tail;           // 1: the last block also builds state/param[waypoint+1] (single GPU)
 };
 
 struct pocs_mc_launch {
@@ -64,8 +61,8 @@ struct pocs_mc_launch {
   int step;                            // k_mc_step: control index; k_mc_fused: number of steps
 };
 
-hipError_t pocs_launch_gmm_sample(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);
-hipError_t pocs_launch_gmm_finalize(const pocs_finalize_launch& a, hipStream_t s);
+hipError_t pocs_launch_gmm_step(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);
+hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t s);
 hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s);
 hipError_t pocs_launch_mc_step(int nblk, const pocs_mc_launch& a, hipStream_t s);
 hipError_t pocs_launch_mc_fused(int nblk, const pocs_mc_launch& a, hipStream_t s);

@@ -1,14 +1,18 @@
 // pocs_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the hot path.
 //
-//   k_gmm_sample    S1+C1+T1  GM_Model::sampleNPoints (GM_Model.h:83-116) + checkMatrixCollisions
-//                             (MCSimulator.h:241-253) + the moment sums truncateGMM needs
-//                             (:592-611), fused: a sample is born, tested and folded into its
-//                             component's (n, sum x, sum x x^T) in registers; the pose and flag are
-//                             streamed out once (24 B + 2 B per evaluation) for audit.
-//   k_gmm_finalize  T1 tail   fixed-shape reduction of the block partials, truncated mean/cov,
-//                             weights (:597-629), per-component EKF predict/update (:766-771,
-//                             :804-812) and Cholesky for the next waypoint -- all on device so
-//                             the waypoint loop never returns to the host.
+//   k_gmm_step      S1+C1+T1  one waypoint of truncateGMM (MCSimulator.h:570-642) in ONE launch:
+//                             head  a dedicated wave folds the previous waypoint's reduced moments
+//                                   into the mixture -- truncated mean/cov, weights (:597-629), the
+//                                   per-component EKF predict/update (:766-771, :804-812), Cholesky --
+//                                   while the sampling waves stage the obstacle table and generate
+//                                   their first normals;
+//                             body  GM_Model::sampleNPoints (GM_Model.h:83-116) + checkMatrixCollisions
+//                                   (:241-253) + the moment sums (:592-611), fused: a sample is born,
+//                                   tested and folded into its component's (n, sum x, sum x x^T) in
+//                                   registers; pose and flag are streamed out once (24 B + 2 B);
+//                             tail  DPP wave reduction -> LDS -> one write-through partial row per
+//                                   block -> the last block to arrive adds the rows in a fixed order.
+//                             The waypoint loop never returns to the host.
 //   k_mc_init       P2+P3     initParticles (:287-297) + first checkParticleCollisions (:333-347)
 //   k_mc_step       P1+P3     moveParticles (:300-322) + checkParticleCollisions, one waypoint,
 //                             particles streamed through HBM (SoA): 24 B in, 24 B out, u32 RMW.
@@ -64,21 +68,61 @@ __device__ __forceinline__ void stage_env(const pocs_env_dev* __restrict__ env, 
   if (threadIdx.x == 0) { *s_fp = env->fp; *s_M = M; }
 }
 
+// Relaxed agent-scope accesses = write-through / L1-bypassing (sc1) on gfx950: what the
+// last-arriver hand-off of the block partials uses instead of a release/acquire fence pair.
+__device__ __forceinline__ void store_wt(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_wt(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(
+      reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Mixture bookkeeping of waypoint `w` (see pocs_gmm_advance_component): lanes < K of the calling
+// wave take one component each, lane 0 then normalises.  Reads state[w-1], moments[w-1] and the
+// chain record of step w-1; writes state[w], param[w].  Called by the last block of k_gmm_step
+// (single GPU) or by k_gmm_advance (waypoint 0, and after the all-reduce when sharded).
+__device__ __forceinline__ void advance_mixture(const pocs_gmm_launch& a, int K, int w, int lane) {
+  const size_t ss = (size_t)K * POCS_STATE_STRIDE, ps = (size_t)K * POCS_PARAM_STRIDE;
+  const int NC = K * POCS_NMOM;
+  double* next = a.state + (size_t)w * ss;
+  double* param = a.param + (size_t)w * ps;
+  if (lane < K) {
+    const double* prev = a.state + (size_t)(w > 0 ? w - 1 : 0) * ss;
+    const double* mom = (w == 0) ? nullptr : a.moments + (size_t)(w - 1) * NC;
+    const double* ch = a.chain + (size_t)(w > 0 ? w - 1 : 0) * POCS_CHAIN_STRIDE;
+    pocs_gmm_advance_component(lane, prev, mom, ch, ch + 3, ch + POCS_CHAIN_Z, a.sensor, next, param);
+  }
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) pocs_gmm_normalise(K, w > 0, next, param);
+}
+
+__global__ __launch_bounds__(64) void k_gmm_advance(pocs_gmm_launch a, int K) {
+  advance_mixture(a, K, a.waypoint, threadIdx.x);
+}
+
 template <int K, bool STORE>
-__global__ __launch_bounds__(POCS_BLOCK) void k_gmm_sample(pocs_gmm_launch a) {
+__global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) {
+  constexpr int NC = K * POCS_NMOM;
   __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
   __shared__ double s_par[K * POCS_PARAM_STRIDE];
-  __shared__ double s_red[POCS_BLOCK / 64][K * POCS_NMOM];
-  __shared__ pocs_footprint s_fp;
-  __shared__ int s_M;
+  __shared__ double s_red[POCS_GMM_BLOCK / 64][NC];
+  __shared__ double s_part[POCS_GMM_BLOCK];
+  __shared__ int s_last;
 
-  stage_env(a.env, s_obs, &s_fp, &s_M);
-  for (int i = threadIdx.x; i < K * POCS_PARAM_STRIDE; i += POCS_BLOCK) s_par[i] = a.param[i];
-  __syncthreads();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int w = a.waypoint;
+  const int M = a.M;
+  const pocs_footprint fp = a.fp;
 
+  // ---- head: stage the obstacle table and this waypoint's sampler parameters in LDS
+  for (int j = tid; j < M * POCS_OBS_STRIDE; j += POCS_GMM_BLOCK) s_obs[j] = a.env->obs[j];
+  for (int j = tid; j < K * POCS_PARAM_STRIDE; j += POCS_GMM_BLOCK)
+    s_par[j] = a.param[(size_t)w * (K * POCS_PARAM_STRIDE) + j];
   const uint64_t seed = a.hdr->seed;
-  const pocs_footprint fp = s_fp;
-  const int M = s_M;
 
   double acc[K][9];
   unsigned nfree[K], ncoll[K];
@@ -88,13 +132,14 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_gmm_sample(pocs_gmm_launch a) {
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[k][j] = 0.0;
   }
+  __syncthreads();
 
-  const long long stride = (long long)gridDim.x * POCS_BLOCK;
-  for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < a.count; i += stride) {
-    const uint64_t gi = (uint64_t)(a.first + i);
+  // ---- body
+  const long long stride = (long long)gridDim.x * POCS_GMM_BLOCK;
+  for (long long i = (long long)blockIdx.x * POCS_GMM_BLOCK + tid; i < a.count; i += stride) {
     double z[3];
     uint32_t spare;
-    pocs_normal3(seed, gi, (uint32_t)a.waypoint, POCS_STREAM_GMM, z, &spare);
+    pocs_normal3(seed, (uint64_t)(a.first + i), (uint32_t)w, POCS_STREAM_GMM, z, &spare);
     // component draw (GM_Model.h:89-93): number of cumulative-weight entries below the uniform
     const double uc = ((double)spare + 0.5) * 0x1p-32;
     int k = 0;
@@ -132,8 +177,7 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_gmm_sample(pocs_gmm_launch a) {
     }
   }
 
-  // wave butterflies -> one row per wave in LDS -> fixed-order sum over the 4 waves
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- tail: wave sums -> one row per wave in LDS -> fixed-order sum over the 4 waves
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const unsigned nf = wave_sum_u32(nfree[k]);
@@ -146,49 +190,52 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_gmm_sample(pocs_gmm_launch a) {
     }
   }
   __syncthreads();
-  if (threadIdx.x < K * POCS_NMOM) {
-    double v = s_red[0][threadIdx.x];
+  if (tid < NC) {
+    double v = s_red[0][tid];
 #pragma unroll
-    for (int w = 1; w < POCS_BLOCK / 64; ++w) v += s_red[w][threadIdx.x];
-    a.partial[(size_t)blockIdx.x * (K * POCS_NMOM) + threadIdx.x] = v;
+    for (int q = 1; q < POCS_GMM_BLOCK / 64; ++q) v += s_red[q][tid];
+    store_wt(&a.partial[(size_t)blockIdx.x * NC + tid], v);
   }
-}
-
-#define POCS_FIN_THREADS 1024
-__global__ __launch_bounds__(POCS_FIN_THREADS) void k_gmm_finalize(pocs_finalize_launch a) {
-  __shared__ double s_part[POCS_FIN_THREADS];
-  const int ncols = a.K * POCS_NMOM;
-  if (a.reduce_wp >= 0) {
-    // slice s of column c sums blocks s, s+S, s+2S, ... ; then the S slice sums are added in order
-    const int S = POCS_FIN_THREADS / ncols;
-    const int s = threadIdx.x / ncols, c = threadIdx.x - s * ncols;
+  // hand-off: every storing wave drains its stores, the block meets, ONE lane takes a ticket;
+  // the block that draws the last ticket reads every row back (L1-bypassing loads) and adds them
+  // in a fixed order: slice q of column c sums rows q, q+S, q+2S, ...; then slices in order.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(&a.ticket[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_last) {
+    constexpr int S = POCS_GMM_BLOCK / NC;
+    const int q = tid / NC, c = tid - q * NC;
     double v = 0.0;
-    if (s < S)
-      for (int b = s; b < a.nblk; b += S) v += a.partial[(size_t)b * ncols + c];
-    s_part[threadIdx.x] = v;
-    __syncthreads();
-    if (threadIdx.x < ncols) {
-      double tot = s_part[threadIdx.x];
-      for (int q = 1; q < S; ++q) tot += s_part[q * ncols + threadIdx.x];
-      a.moments[(size_t)a.reduce_wp * ncols + threadIdx.x] = tot;
+    if (q < S) {
+      const int nb = (int)gridDim.x;
+      for (int b = q; b < nb; b += 8 * S) {        // 8 loads in flight, added in row order
+        double r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int bb = b + u * S;
+          r[u] = (bb < nb) ? load_wt(&a.partial[(size_t)bb * NC + c]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += r[u];
+      }
     }
+    s_part[tid] = v;
     __syncthreads();
-    __threadfence_block();
-  }
-  if (a.advance_wp >= 0) {
-    const int w = a.advance_wp;
-    const size_t ss = (size_t)a.K * POCS_STATE_STRIDE, ps = (size_t)a.K * POCS_PARAM_STRIDE;
-    double* next = a.state + (size_t)w * ss;
-    double* param = a.param + (size_t)w * ps;
-    if ((int)threadIdx.x < a.K) {
-      const double* prev = (w == 0) ? next : a.state + (size_t)(w - 1) * ss;
-      const double* mom = (w == 0) ? nullptr : a.moments + (size_t)(w - 1) * ncols;
-      const double* ch = (w == 0) ? a.chain : a.chain + (size_t)(w - 1) * POCS_CHAIN_STRIDE;
-      pocs_gmm_advance_component(threadIdx.x, prev, mom, ch, ch + 3, ch + POCS_CHAIN_Z, a.sensor,
-                                 next, param);
+    if (tid < NC) {
+      double tot = s_part[tid];
+      for (int r = 1; r < S; ++r) tot += s_part[r * NC + tid];
+      a.moments[(size_t)w * NC + tid] = tot;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) pocs_gmm_normalise(a.K, w > 0, next, param);
+    // single GPU: these ARE the global moments, so carry the mixture to the next waypoint right
+    // here (one wave; the other 255 CUs are already idle) instead of paying another launch
+    if (a.advance_in_tail) {
+      __syncthreads();
+      if (tid < 64) advance_mixture(a, K, w + 1, tid);
+    }
   }
 }
 
@@ -290,14 +337,14 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_count(const uint32_t* __restr
 
 template <int K>
 hipError_t launch_gmm_k(int nblk, const pocs_gmm_launch& a, hipStream_t s) {
-  if (a.store) hipLaunchKernelGGL((k_gmm_sample<K, true>), dim3(nblk), dim3(POCS_BLOCK), 0, s, a);
-  else         hipLaunchKernelGGL((k_gmm_sample<K, false>), dim3(nblk), dim3(POCS_BLOCK), 0, s, a);
+  if (a.store) hipLaunchKernelGGL((k_gmm_step<K, true>), dim3(nblk), dim3(POCS_GMM_BLOCK), 0, s, a);
+  else         hipLaunchKernelGGL((k_gmm_step<K, false>), dim3(nblk), dim3(POCS_GMM_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t pocs_launch_gmm_sample(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s) {
+hipError_t pocs_launch_gmm_step(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s) {
   switch (K) {
     case 1: return launch_gmm_k<1>(nblk, a, s);
     case 2: return launch_gmm_k<2>(nblk, a, s);
@@ -311,8 +358,8 @@ hipError_t pocs_launch_gmm_sample(int K, int nblk, const pocs_gmm_launch& a, hip
   }
 }
 
-hipError_t pocs_launch_gmm_finalize(const pocs_finalize_launch& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_gmm_finalize, dim3(1), dim3(POCS_FIN_THREADS), 0, s, a);
+hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_gmm_advance, dim3(1), dim3(64), 0, s, a, K);
   return hipGetLastError();
 }
 hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s) {
