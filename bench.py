@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--samples", type=int, default=0, help="override samples per GPU (experiments only)")
+    ap.add_argument("--concurrent", type=int, default=1,
+                    help="independent runs kept in flight per GPU (one context + stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=float, default=6.0e7, help="size of the CPU baseline sample")
     args = ap.parse_args()
@@ -113,13 +115,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # optional: R independent runs in flight (the reference's driver performs 200 independent
+    # runs, MCSimulation.py:238-256); each has its own context, stream and buffers, and a host
+    # thread that issues its share of the K steps.  Single-GPU only.
+    extra = []
+    if args.concurrent > 1 and world == 1:
+        import threading
+        for r in range(1, args.concurrent):
+            c2 = pocs_amd.Context(local)
+            c2.configure(plan, env, K=K, N=N, seed=0x5EED0001 + 977 * r)
+            c2.set_shard(0, n_local)
+            extra.append(c2)
+        ctxs = [ctx] + extra
+
+        def run_many(total):
+            def work(c, n):
+                for _ in range(n):
+                    c.run_gmm_estimation() if path == "gmm" else c.run_simulation()
+            share = [total // len(ctxs) + (1 if i < total % len(ctxs) else 0) for i in range(len(ctxs))]
+            th = [threading.Thread(target=work, args=(c, n)) for c, n in zip(ctxs, share) if n]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+
     for _ in range(args.warmup):
         step()
+    if extra:
+        run_many(len(ctxs) * 2)
     fence()
     t0 = time.perf_counter()
     prob = 0.0
-    for _ in range(args.steps):
-        prob = step()
+    if extra:
+        run_many(args.steps)
+        prob = step() if False else 0.0
+    else:
+        for _ in range(args.steps):
+            prob = step()
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -156,12 +188,15 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s path, %s plan (%d waypoints), %d samples per GPU, K=%d, pr2test2 walls, PR2 0.668 m square footprint"
                                    % (args.workload, path.upper(), "bundled trajectory.dat/odometry.dat" if W == 56 else "resampled", W, n_local, K),
-                       "waypoints": W, "samples_per_gpu": n_local, "components": K, "probability": prob},
+                       "waypoints": W, "samples_per_gpu": n_local, "components": K, "probability": prob,
+                       "concurrent_runs": args.concurrent if world == 1 else 1},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(plan, env, K, W, path, args.cpu_evals)
         print(json.dumps(out))
+    for c2 in extra:
+        c2.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

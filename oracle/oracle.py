@@ -80,6 +80,13 @@ class Oracle:
                              C.c_uint32(stream), z, C.byref(sp))
         return list(z), sp.value
 
+    def sample_normals(self, seed, sample, waypoint, stream=STREAM_GMM):
+        z = (C.c_double * 3)()
+        sp = C.c_uint32()
+        self.lib.orc_sample_normals(C.c_uint64(seed), C.c_uint64(sample), C.c_uint32(waypoint),
+                                    C.c_uint32(stream), z, C.byref(sp))
+        return list(z), sp.value
+
     def wrap_angle(self, a):
         return self.lib.orc_wrap_angle(C.c_double(a))
 

@@ -185,6 +185,30 @@ void orc_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stre
   *spare = a[3];
 }
 
+/* mixture samples come in pairs (2j, 2j+1) that share three draws keyed by the pair index j:
+ * slot 0 -> z0,z1 of 2j (+ spare of 2j); slot 1 -> z2 of 2j, z0 of 2j+1 (+ spare of 2j+1);
+ * slot 2 -> z1,z2 of 2j+1.  This returns the normals and spare word of ONE sample. */
+void orc_sample_normals(uint64_t seed, uint64_t sample, uint32_t waypoint, uint32_t stream,
+                        double z[3], uint32_t* spare) {
+  uint64_t pair = sample >> 1;
+  uint32_t w0[4], w1[4], w2[4];
+  double a, b;
+  draw(seed, pair, waypoint, stream, 1, w1);
+  if ((sample & 1) == 0) {
+    draw(seed, pair, waypoint, stream, 0, w0);
+    orc_normal_pair(w0[0], w0[1], w0[2], &z[0], &z[1]);
+    orc_normal_pair(w1[0], w1[1], w1[2], &a, &b);
+    z[2] = a;
+    *spare = w0[3];
+  } else {
+    draw(seed, pair, waypoint, stream, 2, w2);
+    orc_normal_pair(w1[0], w1[1], w1[2], &a, &b);
+    z[0] = b;
+    orc_normal_pair(w2[0], w2[1], w2[2], &z[1], &z[2]);
+    *spare = w1[3];
+  }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* estimator math                                                                              */
 /* ------------------------------------------------------------------------------------------ */
@@ -523,7 +547,7 @@ int orc_gmm_waypoint(const orc_config* cfg, uint64_t seed, int waypoint, const d
   for (long long i = 0; i < count; ++i) {
     double zz[3];
     uint32_t spare;
-    orc_normal3(seed, (uint64_t)(first + i), (uint32_t)waypoint, 3 /* gmm stream */, zz, &spare);
+    orc_sample_normals(seed, (uint64_t)(first + i), (uint32_t)waypoint, 3 /* gmm stream */, zz, &spare);
     double uc = ((double)spare + 0.5) * (1.0 / 4294967296.0);
     int k = 0;
     for (int j = 0; j < K - 1; ++j) if (table[j] < uc) ++k;

@@ -21,7 +21,7 @@
 #include "../../include/pocs.h"
 #include "pocs_kernels.h"
 
-#define POCS_VERSION_STRING "pocs-mi355x 0.1 (gfx950; numerics v1)"
+#define POCS_VERSION_STRING "pocs-mi355x 0.1 (gfx950; numerics v2)"
 
 namespace {
 
@@ -313,6 +313,8 @@ int gmm_shard(pocs_ctx* c, long long* first, long long* count) {
   *count = c->shard_first >= 0 ? c->shard_count : c->num_gmm;
   if (*first < 0 || *count < 0 || *first + *count > c->num_gmm)
     return fail(c, POCS_E_ARG, "shard [%lld,+%lld) outside numGMMSamples=%lld", *first, *count, c->num_gmm);
+  if ((*first & 1) && *count > 0)   // mixture samples 2j, 2j+1 share their random draws: a shard starts on a pair
+    return fail(c, POCS_E_ARG, "GMM shard must start at an even sample index (got %lld)", *first);
   return POCS_OK;
 }
 

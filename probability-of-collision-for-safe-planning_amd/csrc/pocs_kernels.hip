@@ -79,28 +79,49 @@ __device__ __forceinline__ double load_wt(const double* p) {
       reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// Mixture bookkeeping of waypoint `w` (see pocs_gmm_advance_component): lanes < K of the calling
-// wave take one component each, lane 0 then normalises.  Reads state[w-1], moments[w-1] and the
-// chain record of step w-1; writes state[w], param[w].  Called by the last block of k_gmm_step
-// (single GPU) or by k_gmm_advance (waypoint 0, and after the all-reduce when sharded).
-__device__ __forceinline__ void advance_mixture(const pocs_gmm_launch& a, int K, int w, int lane) {
-  const size_t ss = (size_t)K * POCS_STATE_STRIDE, ps = (size_t)K * POCS_PARAM_STRIDE;
-  const int NC = K * POCS_NMOM;
-  double* next = a.state + (size_t)w * ss;
-  double* param = a.param + (size_t)w * ps;
-  if (lane < K) {
-    const double* prev = a.state + (size_t)(w > 0 ? w - 1 : 0) * ss;
-    const double* mom = (w == 0) ? nullptr : a.moments + (size_t)(w - 1) * NC;
-    const double* ch = a.chain + (size_t)(w > 0 ? w - 1 : 0) * POCS_CHAIN_STRIDE;
-    pocs_gmm_advance_component(lane, prev, mom, ch, ch + 3, ch + POCS_CHAIN_Z, a.sensor, next, param);
-  }
+// Mixture bookkeeping of waypoint `w` (see pocs_gmm_advance_component), run by ONE wave: all 64
+// lanes first pull every input (state[w-1], moments[w-1], the chain record of step w-1, the
+// sensor) into LDS in one round trip, lanes < K then take one component each, lane 0 normalises,
+// and the wave writes state[w] / param[w] back together -- two global round trips instead of one
+// per dependent access.  Called by the last block of k_gmm_step (single GPU) or by k_gmm_advance
+// (waypoint 0, and after the all-reduce when sharded).
+#define POCS_ADV_SCRATCH(K) ((K) * (2 * POCS_STATE_STRIDE + POCS_NMOM + POCS_PARAM_STRIDE) + POCS_CHAIN_STRIDE + \
+                             (int)(sizeof(pocs_sensor) / sizeof(double)))
+__device__ __forceinline__ void advance_mixture(const pocs_gmm_launch& a, int K, int w, int lane,
+                                                double* scratch) {
+  const int ss = K * POCS_STATE_STRIDE, ps = K * POCS_PARAM_STRIDE, NC = K * POCS_NMOM;
+  constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
+  double* l_prev = scratch;
+  double* l_mom = l_prev + ss;
+  double* l_ch = l_mom + NC;
+  double* l_sen = l_ch + POCS_CHAIN_STRIDE;
+  double* l_next = l_sen + SEN;
+  double* l_par = l_next + ss;
+  const double* g_prev = a.state + (size_t)(w > 0 ? w - 1 : 0) * ss;
+  const double* g_mom = a.moments + (size_t)(w > 0 ? w - 1 : 0) * NC;
+  const double* g_ch = a.chain + (size_t)(w > 0 ? w - 1 : 0) * POCS_CHAIN_STRIDE;
+  const double* g_sen = reinterpret_cast<const double*>(a.sensor);
+  for (int j = lane; j < ss; j += 64) l_prev[j] = g_prev[j];
+  if (w > 0) for (int j = lane; j < NC; j += 64) l_mom[j] = g_mom[j];
+  for (int j = lane; j < POCS_CHAIN_STRIDE; j += 64) l_ch[j] = g_ch[j];
+  for (int j = lane; j < SEN; j += 64) l_sen[j] = g_sen[j];
   __threadfence_block();
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) pocs_gmm_normalise(K, w > 0, next, param);
+  if (lane < K)
+    pocs_gmm_advance_component(lane, l_prev, (w == 0) ? nullptr : l_mom, l_ch, l_ch + 3, l_ch + POCS_CHAIN_Z,
+                               reinterpret_cast<const pocs_sensor*>(l_sen), l_next, l_par);
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) pocs_gmm_normalise(K, w > 0, l_next, l_par);
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+  for (int j = lane; j < ss; j += 64) a.state[(size_t)w * ss + j] = l_next[j];
+  for (int j = lane; j < ps; j += 64) a.param[(size_t)w * ps + j] = l_par[j];
 }
 
 __global__ __launch_bounds__(64) void k_gmm_advance(pocs_gmm_launch a, int K) {
-  advance_mixture(a, K, a.waypoint, threadIdx.x);
+  __shared__ double s_adv[POCS_ADV_SCRATCH(POCS_MAX_GAUSSIANS)];
+  advance_mixture(a, K, a.waypoint, threadIdx.x, s_adv);
 }
 
 template <int K, bool STORE>
@@ -110,6 +131,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   __shared__ double s_par[K * POCS_PARAM_STRIDE];
   __shared__ double s_red[POCS_GMM_BLOCK / 64][NC];
   __shared__ double s_part[POCS_GMM_BLOCK];
+  __shared__ double s_adv[POCS_ADV_SCRATCH(K)];
   __shared__ int s_last;
 
   const int tid = threadIdx.x;
@@ -134,46 +156,66 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   }
   __syncthreads();
 
-  // ---- body
+  // ---- body: one PAIR of samples (2j, 2j+1) per thread and iteration -- the pair shares three
+  // Philox draws / Box-Muller pairs (pocs_normal3_pair) and its poses leave as 16-byte stores.
+  // a.first is even (checked by the host), so local sample 2*lp is global sample first + 2*lp.
   const long long stride = (long long)gridDim.x * POCS_GMM_BLOCK;
-  for (long long i = (long long)blockIdx.x * POCS_GMM_BLOCK + tid; i < a.count; i += stride) {
-    double z[3];
-    uint32_t spare;
-    pocs_normal3(seed, (uint64_t)(a.first + i), (uint32_t)w, POCS_STREAM_GMM, z, &spare);
-    // component draw (GM_Model.h:89-93): number of cumulative-weight entries below the uniform
-    const double uc = ((double)spare + 0.5) * 0x1p-32;
-    int k = 0;
+  const long long npairs = (a.count + 1) >> 1;
+  const uint64_t pair0 = (uint64_t)(a.first >> 1);
+  for (long long lp = (long long)blockIdx.x * POCS_GMM_BLOCK + tid; lp < npairs; lp += stride) {
+    double zz[2][3];
+    uint32_t spare[2];
+    pocs_normal3_pair(seed, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, zz[0], zz[1], &spare[0], &spare[1]);
+    const long long i0 = 2 * lp;
+    const bool two = (i0 + 1) < a.count;          // false only for the last sample of an odd shard
+    double xs[2], ys[2], ts[2];
+    bool hits[2];
 #pragma unroll
-    for (int j = 0; j < K - 1; ++j) k += (s_par[j * POCS_PARAM_STRIDE + 9] < uc) ? 1 : 0;
-    const double* p = &s_par[k * POCS_PARAM_STRIDE];
-    // mvnrnd (glue_mvnrnd_meat.hpp:134-145): chol_lower * z + mean
-    const double x = fma(p[3], z[0], p[0]);
-    const double y = fma(p[5], z[1], fma(p[4], z[0], p[1]));
-    const double t = fma(p[8], z[2], fma(p[7], z[1], fma(p[6], z[0], p[2])));
-    const bool hit = pocs_pose_collides(x, y, t, &fp, s_obs, M);
-    if (STORE) {
-      a.x[i] = x; a.y[i] = y; a.th[i] = t;
-      a.flags[i] = hit ? (int16_t)1 : (int16_t)0;
+    for (int h = 0; h < 2; ++h) {
+      // component draw (GM_Model.h:89-93): number of cumulative-weight entries below the uniform
+      const double uc = ((double)spare[h] + 0.5) * 0x1p-32;
+      int k = 0;
+#pragma unroll
+      for (int j = 0; j < K - 1; ++j) k += (s_par[j * POCS_PARAM_STRIDE + 9] < uc) ? 1 : 0;
+      const double* p = &s_par[k * POCS_PARAM_STRIDE];
+      // mvnrnd (glue_mvnrnd_meat.hpp:134-145): chol_lower * z + mean
+      const double x = fma(p[3], zz[h][0], p[0]);
+      const double y = fma(p[5], zz[h][1], fma(p[4], zz[h][0], p[1]));
+      const double t = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
+      const bool hit = pocs_pose_collides(x, y, t, &fp, s_obs, M);
+      xs[h] = x; ys[h] = y; ts[h] = t; hits[h] = hit;
+      // T1 sums: acc_k += ind_k * (x, y, t, xx, xy, xt, yy, yt, tt) with ind_k = 1.0 for the
+      // sample's own component when it is collision free, else 0.0; fma(1, v, acc) == acc + v and
+      // fma(0, v, acc) == acc exactly, so this is the masked sum without the select instructions.
+      const bool valid = (h == 0) || two;
+      const double xx = x * x, xy = x * y, xt = x * t, yy = y * y, yt = y * t, tt = t * t;
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        const bool sel = valid && (k == kk);
+        nfree[kk] += (sel && !hit) ? 1u : 0u;
+        ncoll[kk] += (sel && hit) ? 1u : 0u;
+        const double ind = (sel && !hit) ? 1.0 : 0.0;
+        acc[kk][0] = fma(ind, x, acc[kk][0]);
+        acc[kk][1] = fma(ind, y, acc[kk][1]);
+        acc[kk][2] = fma(ind, t, acc[kk][2]);
+        acc[kk][3] = fma(ind, xx, acc[kk][3]);
+        acc[kk][4] = fma(ind, xy, acc[kk][4]);
+        acc[kk][5] = fma(ind, xt, acc[kk][5]);
+        acc[kk][6] = fma(ind, yy, acc[kk][6]);
+        acc[kk][7] = fma(ind, yt, acc[kk][7]);
+        acc[kk][8] = fma(ind, tt, acc[kk][8]);
+      }
     }
-    // T1 sums: acc_k += ind_k * (x, y, t, xx, xy, xt, yy, yt, tt) with ind_k = 1.0 for the
-    // sample's own component when it is collision free, else 0.0; fma(1, v, acc) == acc + v and
-    // fma(0, v, acc) == acc exactly, so this is the masked sum without the select instructions.
-    const double xx = x * x, xy = x * y, xt = x * t, yy = y * y, yt = y * t, tt = t * t;
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) {
-      const bool sel = (k == kk);
-      nfree[kk] += (sel && !hit) ? 1u : 0u;
-      ncoll[kk] += (sel && hit) ? 1u : 0u;
-      const double ind = (sel && !hit) ? 1.0 : 0.0;
-      acc[kk][0] = fma(ind, x, acc[kk][0]);
-      acc[kk][1] = fma(ind, y, acc[kk][1]);
-      acc[kk][2] = fma(ind, t, acc[kk][2]);
-      acc[kk][3] = fma(ind, xx, acc[kk][3]);
-      acc[kk][4] = fma(ind, xy, acc[kk][4]);
-      acc[kk][5] = fma(ind, xt, acc[kk][5]);
-      acc[kk][6] = fma(ind, yy, acc[kk][6]);
-      acc[kk][7] = fma(ind, yt, acc[kk][7]);
-      acc[kk][8] = fma(ind, tt, acc[kk][8]);
+    if (STORE) {
+      if (two) {
+        *reinterpret_cast<double2*>(a.x + i0) = make_double2(xs[0], xs[1]);
+        *reinterpret_cast<double2*>(a.y + i0) = make_double2(ys[0], ys[1]);
+        *reinterpret_cast<double2*>(a.th + i0) = make_double2(ts[0], ts[1]);
+        *reinterpret_cast<int*>(a.flags + i0) = (hits[0] ? 1 : 0) | (hits[1] ? 0x10000 : 0);
+      } else {
+        a.x[i0] = xs[0]; a.y[i0] = ys[0]; a.th[i0] = ts[0];
+        a.flags[i0] = hits[0] ? (int16_t)1 : (int16_t)0;
+      }
     }
   }
 
@@ -234,7 +276,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
     // here (one wave; the other 255 CUs are already idle) instead of paying another launch
     if (a.advance_in_tail) {
       __syncthreads();
-      if (tid < 64) advance_mixture(a, K, w + 1, tid);
+      if (tid < 64) advance_mixture(a, K, w + 1, tid, s_adv);
     }
   }
 }

@@ -166,3 +166,20 @@ POCS_HD void pocs_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint
   pocs_normal_pair(b.x, b.y, b.z, &z[2], &unused);
   *spare = a.w;
 }
+
+// The six standard normals and two spare words of a PAIR of mixture samples (2j, 2j+1), from
+// three draws keyed by the pair index j -- no Box-Muller output is thrown away:
+//   slot 0 -> z0, z1 of sample 2j   (+ its spare word)
+//   slot 1 -> z2 of sample 2j, z0 of sample 2j+1   (+ the spare word of sample 2j+1)
+//   slot 2 -> z1, z2 of sample 2j+1
+POCS_HD void pocs_normal3_pair(uint64_t seed, uint64_t pair, uint32_t waypoint, uint32_t stream,
+                               double za[3], double zb[3], uint32_t* spare_a, uint32_t* spare_b) {
+  const pocs_u32x4 a = pocs_draw(seed, pair, waypoint, stream, 0u);
+  const pocs_u32x4 b = pocs_draw(seed, pair, waypoint, stream, 1u);
+  const pocs_u32x4 c = pocs_draw(seed, pair, waypoint, stream, 2u);
+  pocs_normal_pair(a.x, a.y, a.z, &za[0], &za[1]);
+  pocs_normal_pair(b.x, b.y, b.z, &za[2], &zb[0]);
+  pocs_normal_pair(c.x, c.y, c.z, &zb[1], &zb[2]);
+  *spare_a = a.w;
+  *spare_b = b.w;
+}

@@ -2,8 +2,8 @@
 //
 // Each function names the reference function it stands in for (file:line under
 // /root/reference/mcsimplugin/).  3x3 matrices are row-major double[9].  Matrix products keep
-// the reference's association, (A*B)*C, and a left-to-right three-term inner sum; no operation
-// is contracted (the TU is built with -ffp-contract=off and these use no fma on purpose).
+// the reference's association, (A*B)*C, and a left-to-right inner sum; no operation is
+// contracted (the TU is built with -ffp-contract=off and these use no fma on purpose).
 // Used by: the host chain (pocs_host.hip) and the per-component device update inside
 // k_gmm_finalize (pocs_kernels.hip).
 #pragma once
@@ -42,32 +42,34 @@ POCS_HD void pocs_motion(const double x[3], const double u[3], double out[3]) {
   out[2] = pocs_wrap_angle(x[2] + u[0] + u[2]);
 }
 
-POCS_HD void pocs_mat3_mul(const double* A, const double* B, double* C) {       // C = A*B
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j)
-      C[3 * i + j] = (A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j]) + A[3 * i + 2] * B[6 + j];
-}
-POCS_HD void pocs_mat3_mul_bt(const double* A, const double* B, double* C) {    // C = A*B^T
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j)
-      C[3 * i + j] = (A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1]) + A[3 * i + 2] * B[3 * j + 2];
-}
-
 // EKFpredict(), MCSimulator.h:868-881, with generateG_EKF :517-529, generateV_EKF :453-468
-// (V is copied as written: row 2 = [1 0 1]) and M = diag(Md) from generateM_EKF :495-513.
+// (V is copied as written: row 2 = [1 0 1]) and M = diag(Md) from generateM_EKF :495-513:
+//   R = (V M) V^T,  predSigma = (G Sigma) G^T + R,  predMu = prediction(mu, u).
+// G = I + two entries, V has four and M three non-trivial entries; the products below are the
+// reference's full 3x3 products with the terms that multiply an exact 0 dropped and the
+// multiplications by an exact 1 elided -- the same IEEE values for finite inputs (the oracle keeps
+// the full products; tests/test_product_host_vs_oracle.py compares the two bit for bit).
 POCS_HD void pocs_ekf_predict(const double mu[3], const double S[9], const double u[3],
                               const double Md[3], double pmu[3], double pS[9]) {
   double sn, cs;
   pocs_sincos(mu[2] + u[0], &sn, &cs);
-  const double G[9] = {1, 0, -u[1] * sn, 0, 1, u[1] * cs, 0, 0, 1};
-  const double V[9] = {-u[1] * sn, cs, 0, u[1] * cs, sn, 0, 1, 0, 1};
-  const double M[9] = {Md[0], 0, 0, 0, Md[1], 0, 0, 0, Md[2]};
-  double T[9], R[9], GS[9];
-  pocs_mat3_mul(V, M, T);
-  pocs_mat3_mul_bt(T, V, R);
-  pocs_mat3_mul(G, S, GS);
-  pocs_mat3_mul_bt(GS, G, pS);
-  for (int i = 0; i < 9; ++i) pS[i] = pS[i] + R[i];
+  const double g02 = -u[1] * sn, g12 = u[1] * cs;      // G(0,2), G(1,2); V(0,0) = g02, V(1,0) = g12
+  // GS = G * Sigma
+  const double gs00 = S[0] + g02 * S[6], gs01 = S[1] + g02 * S[7], gs02 = S[2] + g02 * S[8];
+  const double gs10 = S[3] + g12 * S[6], gs11 = S[4] + g12 * S[7], gs12 = S[5] + g12 * S[8];
+  const double gs20 = S[6], gs21 = S[7], gs22 = S[8];
+  // T = V * M  (V = [g02 cs 0; g12 sn 0; 1 0 1])
+  const double t00 = g02 * Md[0], t01 = cs * Md[1];
+  const double t10 = g12 * Md[0], t11 = sn * Md[1];
+  const double t20 = Md[0], t22 = Md[2];
+  // R = T * V^T
+  const double r00 = t00 * g02 + t01 * cs, r01 = t00 * g12 + t01 * sn, r02 = t00;
+  const double r10 = t10 * g02 + t11 * cs, r11 = t10 * g12 + t11 * sn, r12 = t10;
+  const double r20 = t20 * g02, r21 = t20 * g12, r22 = t20 + t22;
+  // predSigma = GS * G^T + R
+  pS[0] = (gs00 + gs02 * g02) + r00; pS[1] = (gs01 + gs02 * g12) + r01; pS[2] = gs02 + r02;
+  pS[3] = (gs10 + gs12 * g02) + r10; pS[4] = (gs11 + gs12 * g12) + r11; pS[5] = gs12 + r12;
+  pS[6] = (gs20 + gs22 * g02) + r20; pS[7] = (gs21 + gs22 * g12) + r21; pS[8] = gs22 + r22;
   pmu[0] = fma(u[1], cs, mu[0]);
   pmu[1] = fma(u[1], sn, mu[1]);
   pmu[2] = pocs_wrap_angle(mu[2] + u[0] + u[2]);
@@ -75,20 +77,20 @@ POCS_HD void pocs_ekf_predict(const double mu[3], const double S[9], const doubl
 
 // EKFupdate(), MCSimulator.h:883-929 (makeHRow :470-492, observation :368-381): one scalar
 // range update per landmark, in landmark order, in place; no angle wrap afterwards.
+//   H = [dx/r dy/r 0],  S = (H Sigma) H^T + Q,  K = (Sigma H^T) S^-1,  mu += K (z - r),
+//   Sigma = (I - K H) Sigma  -- again with the exact-zero terms of H(2) = 0 dropped.
 POCS_HD void pocs_ekf_update(double mu[3], double S[9], const double* z, const pocs_sensor* sen) {
   for (int l = 0; l < sen->L; ++l) {
-    const double dx = mu[0] - sen->lx[l];
+    const double dx = mu[0] - sen->lx[l];          // == -(lx - mu0), makeHRow's numerator
     const double dy = mu[1] - sen->ly[l];
     const double q = dx * dx + dy * dy;
     const double sq = sqrt(q);
-    const double H0 = -(sen->lx[l] - mu[0]) / sq;
-    const double H1 = -(sen->ly[l] - mu[1]) / sq;
-    // S = H Sigma H^T + Q   (1x1);  (H*Sigma) first, then the dot with H
+    const double H0 = dx / sq;
+    const double H1 = dy / sq;
     const double hs0 = H0 * S[0] + H1 * S[3];
     const double hs1 = H0 * S[1] + H1 * S[4];
     const double sinn = (hs0 * H0 + hs1 * H1) + sen->Q;
     const double sinv = 1.0 / sinn;
-    // K = (Sigma H^T) * S^-1
     const double K0 = (S[0] * H0 + S[1] * H1) * sinv;
     const double K1 = (S[3] * H0 + S[4] * H1) * sinv;
     const double K2 = (S[6] * H0 + S[7] * H1) * sinv;
@@ -96,11 +98,15 @@ POCS_HD void pocs_ekf_update(double mu[3], double S[9], const double* z, const p
     mu[0] = mu[0] + K0 * innov;
     mu[1] = mu[1] + K1 * innov;
     mu[2] = mu[2] + K2 * innov;
-    const double A[9] = {1.0 - K0 * H0, 0.0 - K0 * H1, 0, 0.0 - K1 * H0, 1.0 - K1 * H1, 0,
-                         0.0 - K2 * H0, 0.0 - K2 * H1, 1};
-    double N[9];
-    pocs_mat3_mul(A, S, N);
-    for (int i = 0; i < 9; ++i) S[i] = N[i];
+    const double a00 = 1.0 - K0 * H0, a01 = 0.0 - K0 * H1;
+    const double a10 = 0.0 - K1 * H0, a11 = 1.0 - K1 * H1;
+    const double a20 = 0.0 - K2 * H0, a21 = 0.0 - K2 * H1;
+    const double n0 = a00 * S[0] + a01 * S[3], n1 = a00 * S[1] + a01 * S[4], n2 = a00 * S[2] + a01 * S[5];
+    const double n3 = a10 * S[0] + a11 * S[3], n4 = a10 * S[1] + a11 * S[4], n5 = a10 * S[2] + a11 * S[5];
+    const double n6 = (a20 * S[0] + a21 * S[3]) + S[6];
+    const double n7 = (a20 * S[1] + a21 * S[4]) + S[7];
+    const double n8 = (a20 * S[2] + a21 * S[5]) + S[8];
+    S[0] = n0; S[1] = n1; S[2] = n2; S[3] = n3; S[4] = n4; S[5] = n5; S[6] = n6; S[7] = n7; S[8] = n8;
   }
 }
 

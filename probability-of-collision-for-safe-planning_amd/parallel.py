@@ -14,10 +14,15 @@ import numpy as np
 
 
 def shard_range(n_total, rank, world):
-    """Contiguous, balanced split of range(n_total): returns (first, count) of `rank`."""
-    base, rem = divmod(int(n_total), int(world))
-    first = rank * base + min(rank, rem)
-    return first, base + (1 if rank < rem else 0)
+    """Contiguous, balanced split of range(n_total): returns (first, count) of `rank`.
+    Shards start on even indices: mixture samples 2j and 2j+1 share their random draws."""
+    n_total, world = int(n_total), int(world)
+    pairs = (n_total + 1) // 2
+    base, rem = divmod(pairs, world)
+    p0 = rank * base + min(rank, rem)
+    p1 = p0 + base + (1 if rank < rem else 0)
+    lo, hi = min(2 * p0, n_total), min(2 * p1, n_total)
+    return lo, hi - lo
 
 
 def combine_probabilities(colliding_per_waypoint, n_total):

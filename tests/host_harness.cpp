@@ -17,6 +17,10 @@ void hh_sincos_2pi_u32(uint32_t w, double* s, double* c) { pocs_sincos_2pi_u32(w
 void hh_normal3(uint64_t seed, uint64_t idx, uint32_t wp, uint32_t stream, double* z, uint32_t* spare) {
   pocs_normal3(seed, idx, wp, stream, z, spare);
 }
+void hh_normal3_pair(uint64_t seed, uint64_t pair, uint32_t wp, uint32_t stream, double* za, double* zb,
+                     uint32_t* sa, uint32_t* sb) {
+  pocs_normal3_pair(seed, pair, wp, stream, za, zb, sa, sb);
+}
 double hh_wrap(double a) { return pocs_wrap_angle(a); }
 void hh_motion(const double* x, const double* u, double* o) { pocs_motion(x, u, o); }
 void hh_ekf_predict(const double* mu, const double* S, const double* u, const double* Md, double* pm, double* pS) {

@@ -42,6 +42,22 @@ def test_normal3_bitwise(hh, orc):
             assert list(z) == want_z and sp.value == want_sp
 
 
+def test_sample_pairs_bitwise(hh, orc):
+    """Mixture samples 2j and 2j+1 share three draws keyed by the pair index j."""
+    za, zb = (C.c_double * 3)(), (C.c_double * 3)()
+    sa, sb = C.c_uint32(), C.c_uint32()
+    for pair in list(range(100)) + [2 ** 31 - 1, 2 ** 31, 2 ** 39 + 5]:
+        for wp in (0, 7, 499):
+            hh.hh_normal3_pair(C.c_uint64(77), C.c_uint64(pair), C.c_uint32(wp), C.c_uint32(3), za, zb,
+                               C.byref(sa), C.byref(sb))
+            assert (list(za), sa.value) == orc.sample_normals(77, 2 * pair, wp)
+            assert (list(zb), sb.value) == orc.sample_normals(77, 2 * pair + 1, wp)
+    z = np.array([orc.sample_normals(5, i, 3)[0] for i in range(30000)])
+    assert abs(z.mean()) < 0.02 and abs(z.var() - 1) < 0.02
+    assert np.max(np.abs(np.corrcoef(z.T) - np.eye(3))) < 0.02
+    assert abs(np.corrcoef(z[0::2, 2], z[1::2, 0])[0, 1]) < 0.03     # the two halves of slot 1
+
+
 def test_motion_and_wrap_bitwise(hh, orc, plan):
     rng = np.random.default_rng(13)
     o = np.zeros(3)

@@ -97,4 +97,5 @@ def test_shard_range_partitions():
         assert parts[0][0] == 0 and sum(c for _, c in parts) == n
         for (f0, c0), (f1, _) in zip(parts, parts[1:]):
             assert f0 + c0 == f1
-        assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+        assert max(c for _, c in parts) - min(c for _, c in parts) <= 2
+        assert all(f % 2 == 0 for f, c in parts if c > 0)
