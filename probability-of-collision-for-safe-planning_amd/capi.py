@@ -74,11 +74,15 @@ def load_library(build=True):
     global _lib
     if _lib is not None:
         return _lib
-    if build:
-        _build.build_library()
-    if not Path(_build.LIB).exists():
+    import os
+    path = os.environ.get("POCS_LIB")          # tuning only: an alternative build of the same library
+    if not path:
+        if build:
+            _build.build_library()
+        path = str(_build.LIB)
+    if not Path(path).exists():
         raise RuntimeError("libpocs.so is missing and was not built; the HIP path is the only path")
-    lib = C.CDLL(str(_build.LIB))
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res

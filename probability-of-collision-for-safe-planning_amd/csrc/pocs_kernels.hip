@@ -30,32 +30,33 @@
 
 namespace {
 
-// Wave64 sums without LDS traffic: four DPP steps leave every lane of a 16-lane row holding its
-// row's sum (pairs, quads, half rows, rows), then the four row sums are read back through SGPRs
-// and added in row order.  The shape is fixed, so a sum is bitwise reproducible run to run.
+// Row sums by DPP: four steps (pairs, quads, half rows, rows) leave every lane of a 16-lane row
+// holding its row's sum.  Every lane has a valid source in all four patterns, so `old` is never
+// used; the shape is fixed, hence bitwise reproducible run to run.
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi2, lo2);
 }
-__device__ __forceinline__ double lane_f64(double v, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
-                          __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-__device__ __forceinline__ double wave_sum(double v) {
+__device__ __forceinline__ double row_sum(double v) {
   v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
   v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
   v += dpp_f64<0x141>(v);   // row_half_mirror
   v += dpp_f64<0x140>(v);   // row_mirror
-  return ((lane_f64(v, 0) + lane_f64(v, 16)) + lane_f64(v, 32)) + lane_f64(v, 48);
+  return v;
 }
+__device__ __forceinline__ unsigned row_sum_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false);
+  return v;
+}
+// Whole-wave sums (MC count kernel): row sums read back through SGPRs, added in row order.
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);
+  v = row_sum_u32(v);
   return (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16) +
          (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
 }
@@ -129,9 +130,11 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   constexpr int NC = K * POCS_NMOM;
   __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
   __shared__ double s_par[K * POCS_PARAM_STRIDE];
-  __shared__ double s_red[POCS_GMM_BLOCK / 64][NC];
+  __shared__ double s_red[POCS_GMM_BLOCK / 16][NC];     // one row of sums per 16-lane DPP row
   __shared__ double s_part[POCS_GMM_BLOCK];
   __shared__ double s_adv[POCS_ADV_SCRATCH(K)];
+  __shared__ double s_keep[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
+  __shared__ int s_nkeep;
   __shared__ int s_last;
 
   const int tid = threadIdx.x;
@@ -156,6 +159,38 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   }
   __syncthreads();
 
+  // ---- head, part 2: cull the obstacle table against the mixture's bounding box.  A Box-Muller
+  // normal is bounded: u >= 2^-53 gives |z| <= sqrt(106 ln 2) < 8.58, so every pose this launch
+  // can draw lies within mean_k +- 8.58 (|L00|, |L10|+|L11|) of some component; an obstacle whose
+  // inflated box (the broad phase of pocs_box_hit) misses that region is rejected by the broad
+  // phase for every sample, so dropping it here changes no flag.
+  if (tid < 64) {
+    double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const double* p = &s_par[k * POCS_PARAM_STRIDE];
+      const double ex = 8.58 * fabs(p[3]), ey = 8.58 * (fabs(p[4]) + fabs(p[5]));
+      xlo = fmin(xlo, p[0] - ex); xhi = fmax(xhi, p[0] + ex);
+      ylo = fmin(ylo, p[1] - ey); yhi = fmax(yhi, p[1] + ey);
+    }
+    const double pad = sqrt(fp.dx * fp.dx + fp.dy * fp.dy) + 1e-6;   // footprint centre vs base
+    xlo -= pad; xhi += pad; ylo -= pad; yhi += pad;
+    bool keep = false;
+    if (tid < M) {
+      const double* o = &s_obs[tid * POCS_OBS_STRIDE];
+      keep = !(o[0] - o[6] > xhi || o[0] + o[6] < xlo || o[1] - o[7] > yhi || o[1] + o[7] < ylo);
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (keep) {
+      const int pos = __popcll(mask & ((1ull << tid) - 1ull));
+#pragma unroll
+      for (int j = 0; j < POCS_OBS_STRIDE; ++j) s_keep[pos * POCS_OBS_STRIDE + j] = s_obs[tid * POCS_OBS_STRIDE + j];
+    }
+    if (tid == 0) s_nkeep = __popcll(mask);
+  }
+  __syncthreads();
+  const int nkeep = s_nkeep;
+
   // ---- body: one PAIR of samples (2j, 2j+1) per thread and iteration -- the pair shares three
   // Philox draws / Box-Muller pairs (pocs_normal3_pair) and its poses leave as 16-byte stores.
   // a.first is even (checked by the host), so local sample 2*lp is global sample first + 2*lp.
@@ -165,7 +200,16 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   for (long long lp = (long long)blockIdx.x * POCS_GMM_BLOCK + tid; lp < npairs; lp += stride) {
     double zz[2][3];
     uint32_t spare[2];
+#if defined(POCS_ABLATE_RNG)          // timing-only builds (tools/ablate.sh): outputs are wrong
+    for (int h = 0; h < 2; ++h) { zz[h][0] = (double)(lp & 7) * 0.1; zz[h][1] = (double)(lp & 3) * 0.1; zz[h][2] = 0.05; spare[h] = (uint32_t)lp * 2654435761u; }
+#elif defined(POCS_ABLATE_BOXMULLER)
+    { const pocs_u32x4 A = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 0u), B = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 1u),
+                       Cc = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 2u);
+      zz[0][0] = (double)A.x * 0x1p-32; zz[0][1] = (double)A.y * 0x1p-32; zz[0][2] = (double)A.z * 0x1p-32; spare[0] = A.w;
+      zz[1][0] = (double)B.x * 0x1p-32; zz[1][1] = (double)B.y * 0x1p-32; zz[1][2] = (double)(B.z ^ Cc.x ^ Cc.y ^ Cc.z) * 0x1p-32; spare[1] = B.w; }
+#else
     pocs_normal3_pair(seed, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, zz[0], zz[1], &spare[0], &spare[1]);
+#endif
     const long long i0 = 2 * lp;
     const bool two = (i0 + 1) < a.count;          // false only for the last sample of an odd shard
     double xs[2], ys[2], ts[2];
@@ -182,7 +226,11 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
       const double x = fma(p[3], zz[h][0], p[0]);
       const double y = fma(p[5], zz[h][1], fma(p[4], zz[h][0], p[1]));
       const double t = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
+#if defined(POCS_ABLATE_COLLIDE)
+      const bool hit = x > t;
+#else
       const bool hit = pocs_pose_collides(x, y, t, &fp, s_obs, M);
+#endif
       xs[h] = x; ys[h] = y; ts[h] = t; hits[h] = hit;
       // T1 sums: acc_k += ind_k * (x, y, t, xx, xy, xt, yy, yt, tt) with ind_k = 1.0 for the
       // sample's own component when it is collision free, else 0.0; fma(1, v, acc) == acc + v and
@@ -219,23 +267,27 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
     }
   }
 
-  // ---- tail: wave sums -> one row per wave in LDS -> fixed-order sum over the 4 waves
+  // ---- tail: DPP row sums -> one LDS row per 16 lanes -> fixed-order sum over the 32 rows
+  {
+    const int row = tid >> 4;
+    const bool writer = (tid & 15) == 0;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const unsigned nf = wave_sum_u32(nfree[k]);
-    const unsigned nc = wave_sum_u32(ncoll[k]);
-    if (lane == 0) { s_red[wave][k * POCS_NMOM] = (double)nf; s_red[wave][k * POCS_NMOM + 1] = (double)nc; }
+    for (int k = 0; k < K; ++k) {
+      const unsigned nf = row_sum_u32(nfree[k]);
+      const unsigned nc = row_sum_u32(ncoll[k]);
+      if (writer) { s_red[row][k * POCS_NMOM] = (double)nf; s_red[row][k * POCS_NMOM + 1] = (double)nc; }
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const double v = wave_sum(acc[k][j]);
-      if (lane == 0) s_red[wave][k * POCS_NMOM + 2 + j] = v;
+      for (int j = 0; j < 9; ++j) {
+        const double v = row_sum(acc[k][j]);
+        if (writer) s_red[row][k * POCS_NMOM + 2 + j] = v;
+      }
     }
   }
   __syncthreads();
   if (tid < NC) {
     double v = s_red[0][tid];
-#pragma unroll
-    for (int q = 1; q < POCS_GMM_BLOCK / 64; ++q) v += s_red[q][tid];
+#pragma unroll 8
+    for (int q = 1; q < POCS_GMM_BLOCK / 16; ++q) v += s_red[q][tid];
     store_wt(&a.partial[(size_t)blockIdx.x * NC + tid], v);
   }
   // hand-off: every storing wave drains its stores, the block meets, ONE lane takes a ticket;
