@@ -1,0 +1,38 @@
+"""The C++ host-side mirror of the reference's MCModule (csrc/mcmodule.hpp): it compiles against
+include/pocs.h and links with libpocs.so (CPU), and replays MCSimulation.py's command sequence
+with the oracle's answer (GPU)."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+PKG = ROOT / "probability-of-collision-for-safe-planning_amd"
+EXE = ROOT / "tests" / "_mcmodule_demo"
+
+
+@pytest.fixture(scope="module")
+def demo(pocs):
+    pocs.load_library()                                           # builds libpocs.so if needed
+    src = ROOT / "tests" / "mcmodule_demo.cpp"
+    deps = [src, PKG / "csrc" / "mcmodule.hpp", ROOT / "include" / "pocs.h"]
+    if not EXE.exists() or any(d.stat().st_mtime > EXE.stat().st_mtime for d in deps):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-include", "algorithm", str(src), "-o", str(EXE), "-L" + str(PKG),
+                        "-lpocs", "-Wl,-rpath," + str(PKG), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return EXE
+
+
+def test_cpp_module_builds_and_links(demo):
+    out = subprocess.run([str(demo), "--help-only"], capture_output=True, text=True, check=True)
+    assert out.stdout.strip() == "built"
+
+
+@pytest.mark.gpu
+def test_cpp_module_replays_the_reference_sequence(demo, orc, plan, env):
+    out = subprocess.run([str(demo), str(PKG / "data" / "pr2test2_plan.txt"), str(PKG / "data" / "pr2test2_env.txt"),
+                          "3000", "3", "99"], capture_output=True, text=True, check=True)
+    res = dict(ln.split() for ln in out.stdout.strip().splitlines())
+    cfg = orc.config(plan, env, K=3)
+    assert abs(float(res["GMM"]) - orc.run_gmm(cfg, 99, 3000)["prob"]) < 1e-12
+    assert float(res["MC"]) == orc.run_mc(cfg, 99, 3000)[0] / 3000
+    assert res["BADCMD"] == "0" and int(res["HELPLINES"]) == 19
