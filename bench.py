@@ -73,7 +73,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
-    if world > 1:
+    sharded = world > 1 or os.environ.get("POCS_FORCE_SHARDED") == "1"   # rehearse the N>1 path on one GPU
+    if sharded:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -94,7 +95,7 @@ def main():
     ctx = pocs_amd.Context(local)
     ctx.configure(plan, env, K=K, N=N, seed=0x5EED0001)
     engine = None
-    if world > 1:
+    if sharded:
         # one rank per GPU: launches on torch's stream, moments in a torch tensor for all_reduce
         engine = par.GpuEngine(ctx, W, K, N, rank=rank, world=world, per_rank=n_local)
     else:
@@ -102,10 +103,10 @@ def main():
 
     def step():
         if path == "gmm":
-            if world == 1:
+            if not sharded:
                 return ctx.run_gmm_estimation()          # whole run replayed from one hipGraph
             return par.run_gmm_sharded(engine, dist)     # per waypoint: step_local + all_reduce(11K f64)
-        if world == 1:
+        if not sharded:
             return ctx.run_simulation()
         return par.run_mc_sharded(engine, N, dist)       # one all_reduce of the hit count
 
@@ -171,12 +172,21 @@ def main():
         ms_tot += ms
         n_launch += n
     ctx.set_option(pocs_amd.OPT_PROFILE, 0)
-    kern = "k_gmm_sample" if path == "gmm" else "k_mc_step"
+    kern = "k_gmm_step" if path == "gmm" else "k_mc_step"
     bpe = BYTES_PER_EVAL_GMM if path == "gmm" else BYTES_PER_EVAL_MC
     avg_ms = ms_tot / max(n_launch, 1)
     achieved = (bpe * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE
+    # correction applied) are taken offline and committed with their source in profiles/traffic.json
+    traffic, traffic_src = None, None
+    tj = ROOT / "profiles" / "traffic.json"
+    if tj.exists() and not args.samples:
+        rec = json.loads(tj.read_text()).get(args.workload)
+        if rec:
+            traffic, traffic_src = rec["bytes_per_launch"], rec["source"]
     roofline = {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": bpe * n_local,
                 "bytes_per_eval": bpe, "evals_per_launch": n_local, "avg_kernel_us": avg_ms * 1e3,
                 "evals_per_s_in_kernel": n_local / (avg_ms * 1e-3) if avg_ms > 0 else 0.0}
 

@@ -40,7 +40,7 @@ def run_gmm_sharded(engine, dist=None):
     engine.begin()
     for w in range(engine.W):
         engine.step_local(w)
-        if dist is not None and dist.get_world_size() > 1:
+        if dist is not None:
             dist.all_reduce(engine.moments(w))
     return engine.end()
 
@@ -48,7 +48,7 @@ def run_gmm_sharded(engine, dist=None):
 def run_mc_sharded(engine, n_total, dist=None):
     """engine: mc_local() -> tensor [1] int64 with the shard's collided count."""
     cnt = engine.mc_local()
-    if dist is not None and dist.get_world_size() > 1:
+    if dist is not None:
         dist.all_reduce(cnt)
     return int(cnt.item()) / float(n_total)
 
@@ -63,8 +63,8 @@ class GpuEngine:
         first, count = (rank * per_rank, per_rank) if per_rank else shard_range(n_total, rank, world)
         ctx.set_shard(first, count)
         self.count = count
-        if world > 1:
-            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        # launch on torch's current stream so kernels and collectives are ordered without host syncs
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self.buf = torch.zeros(W * K * 11, dtype=torch.float64, device="cuda")
         ctx.gmm_bind_moments(self.buf.data_ptr(), self.buf.numel())
 
