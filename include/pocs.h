@@ -74,6 +74,16 @@ int pocs_send_command(pocs_ctx* ctx, const char* line, char* out, size_t cap);
 #define POCS_OPT_PROFILE 4         /* 1: bracket the hot kernel with hipEvents (see pocs_get_kernel_time) */
 int pocs_set_option(pocs_ctx* ctx, int option, long long value);
 
+/* ---- batches of independent runs (ours) --------------------------------------------------
+ * The reference's driver performs its 200 estimations one after the other
+ * (MCSimulation.py:238-256).  With a batch of R, one pocs_run_gmm_estimation / begin..end
+ * sequence advances R independent estimations in lockstep (one launch per waypoint for all of
+ * them); run i of the batch draws exactly what the i-th of R consecutive single runs would have
+ * drawn.  pocs_run_gmm_estimation returns run 0's probability, pocs_get_batch_probabilities all
+ * R.  The per-waypoint exchange of the step API then covers R x 11K doubles.  MC is not batched. */
+int pocs_set_batch(pocs_ctx* ctx, int runs);
+int pocs_get_batch_probabilities(pocs_ctx* ctx, double* out, int cap);
+
 /* ---- sharding over GPUs (one process per GPU; the caller owns the collective) -----------
  * A context evaluates global sample / particle indices [first, first+count) of the N configured;
  * random draws are keyed by the GLOBAL index so results do not depend on the partition. */

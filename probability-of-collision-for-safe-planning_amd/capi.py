@@ -43,6 +43,8 @@ SIGNATURES = {
     "pocs_run_gmm_estimation": (C.c_int, [_vp, _dp]),
     "pocs_send_command": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_size_t]),
     "pocs_set_option": (C.c_int, [_vp, C.c_int, C.c_longlong]),
+    "pocs_set_batch": (C.c_int, [_vp, C.c_int]),
+    "pocs_get_batch_probabilities": (C.c_int, [_vp, _dp, C.c_int]),
     "pocs_set_shard": (C.c_int, [_vp, C.c_longlong, C.c_longlong]),
     "pocs_set_stream": (C.c_int, [_vp, _vp]),
     "pocs_gmm_begin": (C.c_int, [_vp]),
@@ -187,6 +189,17 @@ class Context:
 
     def set_option(self, opt, val):
         self._chk(self.lib.pocs_set_option(self.h, opt, val))
+
+    def set_batch(self, runs):
+        """Independent GMM estimations advanced in lockstep per run_gmm_estimation / begin..end."""
+        self._chk(self.lib.pocs_set_batch(self.h, runs))
+        self._batch = runs
+
+    def batch_probabilities(self):
+        n = getattr(self, "_batch", 1)
+        out = np.zeros(n)
+        got = self._chk(self.lib.pocs_get_batch_probabilities(self.h, out.ctypes.data_as(_dp), n))
+        return out[:got]
 
     def set_shard(self, first=-1, count=-1):
         """Evaluate global indices [first, first+count); no arguments = the whole range."""

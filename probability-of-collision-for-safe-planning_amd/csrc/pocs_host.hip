@@ -59,6 +59,7 @@ struct pocs_ctx {
   long long shard_first = -1, shard_count = -1;
   long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0;
   unsigned long long epoch = 0;          // bumped by every setter; part of the graph cache key
+  int batch = 1;                         // independent GMM estimations advanced in lockstep per call
 
   // ---- device state ----
   DevBuf d_env, d_sensor, d_hdr, d_chain, d_state, d_param, d_moments, d_partial;
@@ -79,7 +80,8 @@ struct pocs_ctx {
   // ---- results of the last run ----
   std::vector<double> h_chain;           // (W-1) x POCS_CHAIN_STRIDE
   std::vector<double> h_mu, h_cov;       // (W-1) x 3, (W-1) x 9 : main EKF after each step
-  std::vector<double> probs;             // W
+  std::vector<double> probs;             // W (run 0 of the last batch)
+  std::vector<double> batch_probs;       // final probability of every run of the last batch
   std::vector<double> last_moments;      // W x K x 11
   long long last_gmm_count = 0, last_mc_count = 0;
   int last_gmm_wp = -1;
@@ -138,7 +140,22 @@ int grid_blocks(long long count, int block, int default_bpc) {
   if (nb > POCS_MAX_BLOCKS) nb = POCS_MAX_BLOCKS;
   return (int)nb;
 }
-int grid_for(long long count) { return grid_blocks(count, POCS_GMM_BLOCK, 1); }      // k_gmm_step
+// k_gmm_step: blocks PER RUN.  One run alone takes one block per CU (256 partial rows); a batch of
+// R runs shares the chip, so each run gets ~target/R blocks (fewer, fatter blocks: head, tail and
+// partial rows are amortised over more samples).  POCS_GRID_TARGET overrides the total for sweeps.
+int grid_for(long long count, int runs = 1) {
+  static int target = -1;
+  if (target < 0) {
+    const char* e = getenv("POCS_GRID_TARGET");
+    target = e ? atoi(e) : 0;
+    if (target < 0 || target > 8192) target = 0;
+  }
+  const int one = grid_blocks(count, POCS_GMM_BLOCK, 1);
+  if (runs <= 1) return one;
+  int per = ((target ? target : 256) + runs - 1) / runs;      // 256 = one 8-wave block per CU in all
+  if (per < 8) per = 8;
+  return per < one ? per : one;
+}
 int grid_for_mc(long long count) { return grid_blocks(count, POCS_BLOCK, 3); }       // MC kernels
 
 // ---------------------------------------------------------------------------------------------
@@ -253,15 +270,16 @@ int upload_static(pocs_ctx* c) {
   return POCS_OK;
 }
 
-// pinned staging layout (doubles): [0..1] header, then chain, then state0, then moments, total
+// pinned staging layout (doubles): [0 .. 2R) run headers, then R chains, then R initial mixtures,
+// then the moments [W][R][K*11], then the MC total
 struct PinLayout { size_t chain, state0, moments, total, end; };
 PinLayout pin_layout(const pocs_ctx* c) {
   PinLayout p;
-  const size_t W = (size_t)(c->W > 0 ? c->W : 1), K = (size_t)(c->K > 0 ? c->K : 1);
-  p.chain = 2;
-  p.state0 = p.chain + (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE;
-  p.moments = p.state0 + K * POCS_STATE_STRIDE;
-  p.total = p.moments + W * K * POCS_NMOM;
+  const size_t W = (size_t)(c->W > 0 ? c->W : 1), K = (size_t)(c->K > 0 ? c->K : 1), R = (size_t)c->batch;
+  p.chain = 2 * R;
+  p.state0 = p.chain + R * (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE;
+  p.moments = p.state0 + R * K * POCS_STATE_STRIDE;
+  p.total = p.moments + W * R * K * POCS_NMOM;
   p.end = p.total + 2;
   return p;
 }
@@ -276,10 +294,10 @@ int ensure_pin(pocs_ctx* c) {
   return POCS_OK;
 }
 
-uint64_t effective_seed(const pocs_ctx* c) {
+uint64_t effective_seed(const pocs_ctx* c, uint64_t ahead = 0) {
   // every run of a context draws a fresh stream (the reference re-draws on each run*,
   // MCSimulator.h:656-679); setSeed rewinds run_index so (seed, run) is reproducible.
-  return c->seed + 0x9E3779B97F4A7C15ull * c->run_index;
+  return c->seed + 0x9E3779B97F4A7C15ull * (c->run_index + ahead);
 }
 
 double* moments_dev(pocs_ctx* c) { return c->ext_moments ? c->ext_moments : (double*)c->d_moments.p; }
@@ -318,6 +336,8 @@ int gmm_shard(pocs_ctx* c, long long* first, long long* count) {
   return POCS_OK;
 }
 
+long long sample_stride_of(long long count) { return count > 0 ? ((count + 1) & ~1LL) : 2; }   // even
+
 int gmm_prepare(pocs_ctx* c) {
   if (int r = check_common(c)) return r;
   if (c->K < 1) return fail(c, POCS_E_STATE, "setNumGaussians missing");
@@ -325,20 +345,20 @@ int gmm_prepare(pocs_ctx* c) {
   long long first, count;
   if (int r = gmm_shard(c, &first, &count)) return r;
   if (int r = upload_static(c)) return r;
-  const size_t W = (size_t)c->W, K = (size_t)c->K;
-  const int nblk = grid_for(count);
-  if (int r = ensure(c, c->d_hdr, sizeof(pocs_run_header))) return r;
-  if (int r = ensure(c, c->d_chain, (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE * sizeof(double))) return r;
-  if (int r = ensure(c, c->d_state, W * K * POCS_STATE_STRIDE * sizeof(double))) return r;
-  if (int r = ensure(c, c->d_param, W * K * POCS_PARAM_STRIDE * sizeof(double))) return r;
+  const size_t W = (size_t)c->W, K = (size_t)c->K, R = (size_t)c->batch;
+  const int nblk = grid_for(count, c->batch);
+  if (int r = ensure(c, c->d_hdr, R * sizeof(pocs_run_header))) return r;
+  if (int r = ensure(c, c->d_chain, R * (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_state, R * W * K * POCS_STATE_STRIDE * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_param, R * W * K * POCS_PARAM_STRIDE * sizeof(double))) return r;
   if (!c->ext_moments)
-    if (int r = ensure(c, c->d_moments, W * K * POCS_NMOM * sizeof(double))) return r;
-  if (c->ext_moments && c->ext_moments_len < (long long)(W * K * POCS_NMOM))
+    if (int r = ensure(c, c->d_moments, W * R * K * POCS_NMOM * sizeof(double))) return r;
+  if (c->ext_moments && c->ext_moments_len < (long long)(W * R * K * POCS_NMOM))
     return fail(c, POCS_E_BUFFER, "bound moments buffer too small");
-  if (int r = ensure(c, c->d_partial, (size_t)nblk * K * POCS_NMOM * sizeof(double))) return r;
-  if (int r = ensure(c, c->d_ticket, W * sizeof(unsigned))) return r;
+  if (int r = ensure(c, c->d_partial, R * (size_t)nblk * K * POCS_NMOM * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_ticket, R * W * sizeof(unsigned))) return r;
   if (c->opt_store) {
-    const size_t n = (size_t)(count > 0 ? count : 1);
+    const size_t n = R * (size_t)sample_stride_of(count);
     if (int r = ensure(c, c->d_sx, n * sizeof(double))) return r;
     if (int r = ensure(c, c->d_sy, n * sizeof(double))) return r;
     if (int r = ensure(c, c->d_st, n * sizeof(double))) return r;
@@ -349,30 +369,36 @@ int gmm_prepare(pocs_ctx* c) {
 
 // host staging -> device: run header, chain, initial mixture (initGMM, MCSimulator.h:350-352,
 // GM_Model.h:57-77: K copies of (mu0, Sigma0), weights 1/K)
-int gmm_upload_run(pocs_ctx* c, uint64_t seed) {
-  compute_chain(c, seed);
+int gmm_upload_run(pocs_ctx* c) {
   const PinLayout pl = pin_layout(c);
   double* pin = (double*)c->h_pin;
-  pocs_run_header hdr; hdr.seed = seed; hdr.pad = 0;
-  memcpy(pin, &hdr, sizeof hdr);
-  memcpy(pin + pl.chain, c->h_chain.data(), c->h_chain.size() * sizeof(double));
-  const int W = c->W;
-  for (int k = 0; k < c->K; ++k) {
-    double* s = pin + pl.state0 + (size_t)k * POCS_STATE_STRIDE;
-    s[0] = c->traj[0]; s[1] = c->traj[W]; s[2] = c->traj[2 * W];
-    memcpy(s + 3, c->cov0, 9 * sizeof(double));
-    s[12] = 1.0 / c->K; s[13] = 1.0; s[14] = 0.0; s[15] = 0.0;
+  const int W = c->W, R = c->batch;
+  const size_t steps = (size_t)(W > 1 ? W - 1 : 1);
+  std::vector<double> chain0, mu0, cov0;
+  for (int r = R - 1; r >= 0; --r) {          // run 0 last: c->h_chain / h_mu / h_cov keep ITS chain
+    const uint64_t seed = effective_seed(c, (uint64_t)r);
+    compute_chain(c, seed);
+    pocs_run_header hdr; hdr.seed = seed; hdr.pad = 0;
+    memcpy(pin + 2 * (size_t)r, &hdr, sizeof hdr);
+    memcpy(pin + pl.chain + (size_t)r * steps * POCS_CHAIN_STRIDE, c->h_chain.data(), c->h_chain.size() * sizeof(double));
+    for (int k = 0; k < c->K; ++k) {
+      double* s = pin + pl.state0 + ((size_t)r * c->K + k) * POCS_STATE_STRIDE;
+      s[0] = c->traj[0]; s[1] = c->traj[W]; s[2] = c->traj[2 * W];
+      memcpy(s + 3, c->cov0, 9 * sizeof(double));
+      s[12] = 1.0 / c->K; s[13] = 1.0; s[14] = 0.0; s[15] = 0.0;
+    }
   }
-  HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, pin, sizeof hdr, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_chain.p, pin + pl.chain, c->h_chain.size() * sizeof(double),
+  c->run_index += (uint64_t)R;
+  HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, pin, (size_t)R * sizeof(pocs_run_header), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_chain.p, pin + pl.chain, (size_t)R * steps * POCS_CHAIN_STRIDE * sizeof(double),
                            hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_state.p, pin + pl.state0, (size_t)c->K * POCS_STATE_STRIDE * sizeof(double),
-                           hipMemcpyHostToDevice, c->stream));
+  // the initial mixture of run r goes to state[r][0]: R rows of K*16 doubles, pitch W*K*16
+  const size_t row = (size_t)c->K * POCS_STATE_STRIDE * sizeof(double);
+  HIPCHK(c, hipMemcpy2DAsync(c->d_state.p, (size_t)W * row, pin + pl.state0, row, row, (size_t)R,
+                             hipMemcpyHostToDevice, c->stream));
   return POCS_OK;
 }
 
-// One waypoint = one launch of k_gmm_step: its head folds moments[w-1] (already reduced, by the
-// previous launch's last block and -- across GPUs -- by the caller's all-reduce) into the mixture.
 void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long count, int w) {
   memset(a, 0, sizeof *a);
   a->hdr = (const pocs_run_header*)c->d_hdr.p;
@@ -389,6 +415,8 @@ void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long
   a->first = first; a->count = count;
   a->fp = c->fp; a->M = (int)(c->boxes.size() / 5);
   a->waypoint = w; a->store = c->opt_store ? 1 : 0;
+  a->sample_stride = sample_stride_of(count);
+  a->nruns = c->batch; a->W = c->W;
 }
 
 // state/param[w] from state/moments[w-1]: its own tiny launch for waypoint 0 and, when sharded,
@@ -412,42 +440,50 @@ int enqueue_step(pocs_ctx* c, int nblk, long long first, long long count, int w,
 }
 
 int enqueue_ticket_reset(pocs_ctx* c) {
-  HIPCHK(c, hipMemsetAsync(c->d_ticket.p, 0, (size_t)c->W * sizeof(unsigned), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_ticket.p, 0, (size_t)c->batch * c->W * sizeof(unsigned), c->stream));
   return POCS_OK;
 }
 
 int enqueue_gmm_all(pocs_ctx* c, long long first, long long count, bool prof) {
-  const int W = c->W, nblk = grid_for(count);
+  const int W = c->W, nblk = grid_for(count, c->batch);
   if (int r = enqueue_ticket_reset(c)) return r;
   if (int r = enqueue_advance(c, 0)) return r;
   for (int w = 0; w < W; ++w)
     if (int r = enqueue_step(c, nblk, first, count, w, true, prof ? w : -1)) return r;
   const PinLayout pl = pin_layout(c);
   HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.moments, moments_dev(c),
-                           (size_t)W * c->K * POCS_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                           (size_t)W * c->batch * c->K * POCS_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   return POCS_OK;
 }
 
 // F1 (MCSimulator.h:848-856): p_w = colliding / numGMMSamples (:633-641), result = 1 - prod(1 - p_w)
 void gmm_combine(pocs_ctx* c, const double* moments, double* probability) {
-  const int W = c->W, K = c->K;
+  const int W = c->W, K = c->K, R = c->batch;          // moments: [W][R][K*11]
   c->probs.assign(W, 0.0);
-  c->last_moments.assign(moments, moments + (size_t)W * K * POCS_NMOM);
-  double prod = 1.0;
-  for (int w = 0; w < W; ++w) {
-    double coll = 0.0;
-    for (int k = 0; k < K; ++k) coll += moments[((size_t)w * K + k) * POCS_NMOM + 1];
-    const double p = coll / (1.0 * (double)c->num_gmm);
-    c->probs[w] = p;
-    prod *= (1.0 - p);
+  c->batch_probs.assign(R, 0.0);
+  c->last_moments.assign((size_t)W * K * POCS_NMOM, 0.0);
+  for (int r = 0; r < R; ++r) {
+    double prod = 1.0;
+    for (int w = 0; w < W; ++w) {
+      const double* m = moments + ((size_t)w * R + r) * K * POCS_NMOM;
+      double coll = 0.0;
+      for (int k = 0; k < K; ++k) coll += m[(size_t)k * POCS_NMOM + 1];
+      const double p = coll / (1.0 * (double)c->num_gmm);
+      prod *= (1.0 - p);
+      if (r == 0) {
+        c->probs[w] = p;
+        memcpy(&c->last_moments[(size_t)w * K * POCS_NMOM], m, (size_t)K * POCS_NMOM * sizeof(double));
+      }
+    }
+    c->batch_probs[r] = 1.0 - prod;
   }
-  *probability = 1.0 - prod;
+  *probability = c->batch_probs[0];
 }
 
 std::string config_key(const pocs_ctx* c, long long first, long long count, const char* tag) {
   char buf[256];
-  snprintf(buf, sizeof buf, "%s e%llu W%d K%d n%lld f%lld c%lld s%lld fu%lld st%p em%p", tag, c->epoch,
-           c->W, c->K, c->num_gmm, first, count, c->opt_store, c->opt_fused, (void*)c->stream,
+  snprintf(buf, sizeof buf, "%s e%llu W%d K%d R%d n%lld f%lld c%lld s%lld fu%lld st%p em%p", tag, c->epoch,
+           c->W, c->K, c->batch, c->num_gmm, first, count, c->opt_store, c->opt_fused, (void*)c->stream,
            (void*)c->ext_moments);
   return buf;
 }
@@ -457,9 +493,7 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
   if (int r = gmm_prepare(c)) return r;
   long long first, count;
   if (int r = gmm_shard(c, &first, &count)) return r;
-  const uint64_t seed = effective_seed(c);
-  c->run_index++;
-  if (int r = gmm_upload_run(c, seed)) return r;
+  if (int r = gmm_upload_run(c)) return r;
   const bool prof = c->opt_profile != 0;
   if (int r = prof_begin(c, (size_t)c->W)) return r;
   if (c->opt_graph && !prof) {
@@ -554,7 +588,7 @@ int run_mc_local(pocs_ctx* c, unsigned long long* collided) {
   const uint64_t seed = effective_seed(c);
   c->run_index++;
   compute_chain(c, seed);
-  const PinLayout pl = pin_layout(c);
+  const PinLayout pl = pin_layout(c);       // MC always evaluates one run (slot 0 of the staging area)
   double* pin = (double*)c->h_pin;
   pocs_run_header hdr; hdr.seed = seed; hdr.pad = 0;
   memcpy(pin, &hdr, sizeof hdr);
@@ -641,6 +675,7 @@ const char* kHelp =
     "setFootprint     dx dy half_x half_y (new)\n"
     "addObstacle      cx cy half_x half_y yaw_rad (new)\n"
     "clearObstacles   (new)\n"
+    "setBatch         r: independent GMM estimations advanced in lockstep per runGMMEstimation (new)\n"
     "help             this text\n";
 
 }  // namespace
@@ -830,6 +865,22 @@ int pocs_set_option(pocs_ctx* c, int option, long long value) {
   return POCS_OK;
 }
 
+int pocs_set_batch(pocs_ctx* c, int runs) {
+  if (!c) return POCS_E_ARG;
+  c->epoch++;
+  if (runs < 1 || runs > 256) return fail(c, POCS_E_ARG, "batch %d outside 1..256", runs);
+  if (c->gmm_open) return fail(c, POCS_E_ORDER, "pocs_set_batch inside a begin/end sequence");
+  c->batch = runs;
+  return POCS_OK;
+}
+
+int pocs_get_batch_probabilities(pocs_ctx* c, double* out, int cap) {
+  if (!c || !out) return POCS_E_ARG;
+  if ((int)c->batch_probs.size() > cap) return fail(c, POCS_E_BUFFER, "need %zu doubles", c->batch_probs.size());
+  memcpy(out, c->batch_probs.data(), c->batch_probs.size() * sizeof(double));
+  return (int)c->batch_probs.size();
+}
+
 int pocs_set_shard(pocs_ctx* c, long long first, long long count) {
   if (c) c->epoch++;
   if (!c) return POCS_E_ARG;
@@ -882,9 +933,7 @@ int pocs_gmm_begin(pocs_ctx* c) {
   if (!c) return POCS_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   if (int r = gmm_prepare(c)) return r;
-  const uint64_t seed = effective_seed(c);
-  c->run_index++;
-  if (int r = gmm_upload_run(c, seed)) return r;
+  if (int r = gmm_upload_run(c)) return r;
   if (int r = prof_begin(c, (size_t)c->W)) return r;
   if (int r = enqueue_ticket_reset(c)) return r;
   c->gmm_open = true;
@@ -899,7 +948,7 @@ int pocs_gmm_step_local(pocs_ctx* c, int w) {
   long long first, count;
   if (int r = gmm_shard(c, &first, &count)) return r;
   if (int r = enqueue_advance(c, w)) return r;        // folds the (reduced) moments of w-1
-  if (int r = enqueue_step(c, grid_for(count), first, count, w, false, c->opt_profile ? w : -1)) return r;
+  if (int r = enqueue_step(c, grid_for(count, c->batch), first, count, w, false, c->opt_profile ? w : -1)) return r;
   c->last_gmm_wp = w;
   c->last_gmm_count = count;
   return POCS_OK;
@@ -908,10 +957,10 @@ int pocs_gmm_step_local(pocs_ctx* c, int w) {
 void* pocs_gmm_moments_ptr(pocs_ctx* c, int w) {
   if (!c || w < 0 || w >= c->W || c->K < 1) return nullptr;
   double* m = moments_dev(c);
-  return m ? m + (size_t)w * c->K * POCS_NMOM : nullptr;
+  return m ? m + (size_t)w * c->batch * c->K * POCS_NMOM : nullptr;
 }
 
-int pocs_gmm_moments_len(const pocs_ctx* c) { return (c && c->K > 0) ? c->K * POCS_NMOM : 0; }
+int pocs_gmm_moments_len(const pocs_ctx* c) { return (c && c->K > 0) ? c->batch * c->K * POCS_NMOM : 0; }
 
 int pocs_gmm_end(pocs_ctx* c, double* probability) {
   if (!c) return POCS_E_ARG;
@@ -920,7 +969,7 @@ int pocs_gmm_end(pocs_ctx* c, double* probability) {
   if (!probability) return fail(c, POCS_E_ARG, "null output");
   const PinLayout pl = pin_layout(c);
   HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.moments, moments_dev(c),
-                           (size_t)c->W * c->K * POCS_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                           (size_t)c->W * c->batch * c->K * POCS_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (int r = prof_collect(c, (size_t)c->W)) return r;
   gmm_combine(c, (double*)c->h_pin + pl.moments, probability);
@@ -1089,6 +1138,7 @@ int pocs_send_command(pocs_ctx* c, const char* line, char* out, size_t cap) {
     return pocs_set_obstacles(c, b.data(), (int)(b.size() / 5));
   }
   if (name == "clearObstacles") return pocs_set_obstacles(c, nullptr, 0);
+  if (name == "setBatch") { if (int r = one_int(&n)) return r; return pocs_set_batch(c, (int)n); }
   if (name == "runSimulation" || name == "runGMMEstimation") {                 // :75-81, :66-72
     double p = 0.0;
     const int r = (name == "runSimulation") ? pocs_run_simulation(c, &p) : pocs_run_gmm_estimation(c, &p);

@@ -28,20 +28,25 @@ struct pocs_run_header {         // per-run scalars read by every kernel (so a c
   uint64_t pad;
 };
 
+// Arrays carry a leading "run" dimension: a launch advances `nruns` independent estimations (the
+// reference's driver performs 200 of them one after the other, MCSimulation.py:238-256) in lockstep.
 struct pocs_gmm_launch {
-  const pocs_run_header* hdr;
+  const pocs_run_header* hdr;    // [nruns] per-run seeds
   const pocs_env_dev* env;       // obstacle table (records only; M and the footprint travel below)
-  const double* chain;           // [W-1][POCS_CHAIN_STRIDE]
+  const double* chain;           // [nruns][W-1][POCS_CHAIN_STRIDE]
   const pocs_sensor* sensor;
-  double* state;                 // [W][K*POCS_STATE_STRIDE]  mixture sampled at each waypoint
-  double* param;                 // [W][K*POCS_PARAM_STRIDE]  its sampler parameters (audit copy)
-  double* moments;               // [W][K*POCS_NMOM]          reduced moments of each waypoint
-  double* partial;               // [gridDim.x][K*POCS_NMOM]  block partials of this launch
-  unsigned* ticket;              // [W] arrival counters, zeroed once per run
-  double* x; double* y; double* th;   // SoA sample buffers of this shard (unused when !store)
+  double* state;                 // [nruns][W][K*POCS_STATE_STRIDE]  mixture sampled at each waypoint
+  double* param;                 // [nruns][W][K*POCS_PARAM_STRIDE]  its sampler parameters
+  double* moments;               // [W][nruns][K*POCS_NMOM]          reduced moments of each waypoint
+  double* partial;               // [nruns][gridDim.x][K*POCS_NMOM]  block partials of this launch
+  unsigned* ticket;              // [nruns][W] arrival counters, zeroed once per batch
+  double* x; double* y; double* th;   // SoA sample buffers [nruns][sample_stride] (unused when !store)
   int16_t* flags;
   long long first;               // global index of the shard's first sample
   long long count;               // samples in this shard
+  long long sample_stride;       // even, >= count
+  int nruns;
+  int W;
   pocs_footprint fp;
   int M;
   int waypoint;

@@ -88,7 +88,7 @@ __device__ __forceinline__ double load_wt(const double* p) {
 // (waypoint 0, and after the all-reduce when sharded).
 #define POCS_ADV_SCRATCH(K) ((K) * (2 * POCS_STATE_STRIDE + POCS_NMOM + POCS_PARAM_STRIDE) + POCS_CHAIN_STRIDE + \
                              (int)(sizeof(pocs_sensor) / sizeof(double)))
-__device__ __forceinline__ void advance_mixture(const pocs_gmm_launch& a, int K, int w, int lane,
+__device__ __forceinline__ void advance_mixture(const pocs_gmm_launch& a, int K, int w, int r, int lane,
                                                 double* scratch) {
   const int ss = K * POCS_STATE_STRIDE, ps = K * POCS_PARAM_STRIDE, NC = K * POCS_NMOM;
   constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
@@ -98,9 +98,13 @@ __device__ __forceinline__ void advance_mixture(const pocs_gmm_launch& a, int K,
   double* l_sen = l_ch + POCS_CHAIN_STRIDE;
   double* l_next = l_sen + SEN;
   double* l_par = l_next + ss;
-  const double* g_prev = a.state + (size_t)(w > 0 ? w - 1 : 0) * ss;
-  const double* g_mom = a.moments + (size_t)(w > 0 ? w - 1 : 0) * NC;
-  const double* g_ch = a.chain + (size_t)(w > 0 ? w - 1 : 0) * POCS_CHAIN_STRIDE;
+  // run r of the batch: state/param [r][W][..], moments [W][R][..] (one all-reduce per waypoint
+  // covers every run), chain [r][W-1][..]
+  double* g_state = a.state + (size_t)r * a.W * ss;
+  double* g_param = a.param + (size_t)r * a.W * ps;
+  const double* g_prev = g_state + (size_t)(w > 0 ? w - 1 : 0) * ss;
+  const double* g_mom = a.moments + ((size_t)(w > 0 ? w - 1 : 0) * a.nruns + r) * NC;
+  const double* g_ch = a.chain + ((size_t)r * (a.W > 1 ? a.W - 1 : 1) + (w > 0 ? w - 1 : 0)) * POCS_CHAIN_STRIDE;
   const double* g_sen = reinterpret_cast<const double*>(a.sensor);
   for (int j = lane; j < ss; j += 64) l_prev[j] = g_prev[j];
   if (w > 0) for (int j = lane; j < NC; j += 64) l_mom[j] = g_mom[j];
@@ -116,13 +120,13 @@ __device__ __forceinline__ void advance_mixture(const pocs_gmm_launch& a, int K,
   if (lane == 0) pocs_gmm_normalise(K, w > 0, l_next, l_par);
   __threadfence_block();
   __builtin_amdgcn_wave_barrier();
-  for (int j = lane; j < ss; j += 64) a.state[(size_t)w * ss + j] = l_next[j];
-  for (int j = lane; j < ps; j += 64) a.param[(size_t)w * ps + j] = l_par[j];
+  for (int j = lane; j < ss; j += 64) g_state[(size_t)w * ss + j] = l_next[j];
+  for (int j = lane; j < ps; j += 64) g_param[(size_t)w * ps + j] = l_par[j];
 }
 
 __global__ __launch_bounds__(64) void k_gmm_advance(pocs_gmm_launch a, int K) {
   __shared__ double s_adv[POCS_ADV_SCRATCH(POCS_MAX_GAUSSIANS)];
-  advance_mixture(a, K, a.waypoint, threadIdx.x, s_adv);
+  advance_mixture(a, K, a.waypoint, blockIdx.x, threadIdx.x, s_adv);      // one block per run
 }
 
 template <int K, bool STORE>
@@ -138,16 +142,16 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   __shared__ int s_last;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
   const int w = a.waypoint;
+  const int r = blockIdx.y;                 // run of the batch (independent estimations in lockstep)
   const int M = a.M;
   const pocs_footprint fp = a.fp;
 
   // ---- head: stage the obstacle table and this waypoint's sampler parameters in LDS
   for (int j = tid; j < M * POCS_OBS_STRIDE; j += POCS_GMM_BLOCK) s_obs[j] = a.env->obs[j];
   for (int j = tid; j < K * POCS_PARAM_STRIDE; j += POCS_GMM_BLOCK)
-    s_par[j] = a.param[(size_t)w * (K * POCS_PARAM_STRIDE) + j];
-  const uint64_t seed = a.hdr->seed;
+    s_par[j] = a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j];
+  const uint64_t seed = a.hdr[r].seed;
 
   double acc[K][9];
   unsigned nfree[K], ncoll[K];
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
 #if defined(POCS_ABLATE_COLLIDE)
       const bool hit = x > t;
 #else
-      const bool hit = pocs_pose_collides(x, y, t, &fp, s_obs, M);
+      const bool hit = pocs_pose_collides(x, y, t, &fp, s_keep, nkeep);
 #endif
       xs[h] = x; ys[h] = y; ts[h] = t; hits[h] = hit;
       // T1 sums: acc_k += ind_k * (x, y, t, xx, xy, xt, yy, yt, tt) with ind_k = 1.0 for the
@@ -255,14 +259,15 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
       }
     }
     if (STORE) {
+      const size_t o = (size_t)r * a.sample_stride + (size_t)i0;      // sample_stride is even
       if (two) {
-        *reinterpret_cast<double2*>(a.x + i0) = make_double2(xs[0], xs[1]);
-        *reinterpret_cast<double2*>(a.y + i0) = make_double2(ys[0], ys[1]);
-        *reinterpret_cast<double2*>(a.th + i0) = make_double2(ts[0], ts[1]);
-        *reinterpret_cast<int*>(a.flags + i0) = (hits[0] ? 1 : 0) | (hits[1] ? 0x10000 : 0);
+        *reinterpret_cast<double2*>(a.x + o) = make_double2(xs[0], xs[1]);
+        *reinterpret_cast<double2*>(a.y + o) = make_double2(ys[0], ys[1]);
+        *reinterpret_cast<double2*>(a.th + o) = make_double2(ts[0], ts[1]);
+        *reinterpret_cast<int*>(a.flags + o) = (hits[0] ? 1 : 0) | (hits[1] ? 0x10000 : 0);
       } else {
-        a.x[i0] = xs[0]; a.y[i0] = ys[0]; a.th[i0] = ts[0];
-        a.flags[i0] = hits[0] ? (int16_t)1 : (int16_t)0;
+        a.x[o] = xs[0]; a.y[o] = ys[0]; a.th[o] = ts[0];
+        a.flags[o] = hits[0] ? (int16_t)1 : (int16_t)0;
       }
     }
   }
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
     double v = s_red[0][tid];
 #pragma unroll 8
     for (int q = 1; q < POCS_GMM_BLOCK / 16; ++q) v += s_red[q][tid];
-    store_wt(&a.partial[(size_t)blockIdx.x * NC + tid], v);
+    store_wt(&a.partial[((size_t)r * gridDim.x + blockIdx.x) * NC + tid], v);
   }
   // hand-off: every storing wave drains its stores, the block meets, ONE lane takes a ticket;
   // the block that draws the last ticket reads every row back (L1-bypassing loads) and adds them
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const unsigned t = __hip_atomic_fetch_add(&a.ticket[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_fetch_add(&a.ticket[(size_t)r * a.W + w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == gridDim.x - 1u) ? 1 : 0;
   }
   __syncthreads();
@@ -307,28 +312,28 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
     if (q < S) {
       const int nb = (int)gridDim.x;
       for (int b = q; b < nb; b += 8 * S) {        // 8 loads in flight, added in row order
-        double r[8];
+        double rows[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int bb = b + u * S;
-          r[u] = (bb < nb) ? load_wt(&a.partial[(size_t)bb * NC + c]) : 0.0;
+          rows[u] = (bb < nb) ? load_wt(&a.partial[((size_t)r * nb + bb) * NC + c]) : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v += r[u];
+        for (int u = 0; u < 8; ++u) v += rows[u];
       }
     }
     s_part[tid] = v;
     __syncthreads();
     if (tid < NC) {
       double tot = s_part[tid];
-      for (int r = 1; r < S; ++r) tot += s_part[r * NC + tid];
-      a.moments[(size_t)w * NC + tid] = tot;
+      for (int sl = 1; sl < S; ++sl) tot += s_part[sl * NC + tid];
+      a.moments[((size_t)w * a.nruns + r) * NC + tid] = tot;
     }
     // single GPU: these ARE the global moments, so carry the mixture to the next waypoint right
     // here (one wave; the other 255 CUs are already idle) instead of paying another launch
     if (a.advance_in_tail) {
       __syncthreads();
-      if (tid < 64) advance_mixture(a, K, w + 1, tid, s_adv);
+      if (tid < 64) advance_mixture(a, K, w + 1, r, tid, s_adv);
     }
   }
 }
@@ -431,8 +436,8 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_count(const uint32_t* __restr
 
 template <int K>
 hipError_t launch_gmm_k(int nblk, const pocs_gmm_launch& a, hipStream_t s) {
-  if (a.store) hipLaunchKernelGGL((k_gmm_step<K, true>), dim3(nblk), dim3(POCS_GMM_BLOCK), 0, s, a);
-  else         hipLaunchKernelGGL((k_gmm_step<K, false>), dim3(nblk), dim3(POCS_GMM_BLOCK), 0, s, a);
+  if (a.store) hipLaunchKernelGGL((k_gmm_step<K, true>), dim3(nblk, a.nruns), dim3(POCS_GMM_BLOCK), 0, s, a);
+  else         hipLaunchKernelGGL((k_gmm_step<K, false>), dim3(nblk, a.nruns), dim3(POCS_GMM_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 
@@ -453,7 +458,7 @@ hipError_t pocs_launch_gmm_step(int K, int nblk, const pocs_gmm_launch& a, hipSt
 }
 
 hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_gmm_advance, dim3(1), dim3(64), 0, s, a, K);
+  hipLaunchKernelGGL(k_gmm_advance, dim3(a.nruns), dim3(64), 0, s, a, K);
   return hipGetLastError();
 }
 hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s) {

@@ -57,15 +57,17 @@ class GpuEngine:
     """A libpocs context bound to this rank's GPU, torch's current stream and a torch-owned
     moments buffer (so all_reduce can take views of it)."""
 
-    def __init__(self, ctx, W, K, n_total, rank=0, world=1, per_rank=None):
+    def __init__(self, ctx, W, K, n_total, rank=0, world=1, per_rank=None, batch=1):
         import torch
         self.ctx, self.W, self.K, self.torch = ctx, W, K, torch
+        self.batch = batch                     # independent runs advanced in lockstep (pocs_set_batch)
+        ctx.set_batch(batch)
         first, count = (rank * per_rank, per_rank) if per_rank else shard_range(n_total, rank, world)
         ctx.set_shard(first, count)
         self.count = count
         # launch on torch's current stream so kernels and collectives are ordered without host syncs
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.buf = torch.zeros(W * K * 11, dtype=torch.float64, device="cuda")
+        self.buf = torch.zeros(W * batch * K * 11, dtype=torch.float64, device="cuda")   # [W][batch][K*11]
         ctx.gmm_bind_moments(self.buf.data_ptr(), self.buf.numel())
 
     def begin(self):
@@ -75,11 +77,14 @@ class GpuEngine:
         self.ctx.gmm_step_local(w)
 
     def moments(self, w):
-        n = self.K * 11
+        n = self.batch * self.K * 11           # one exchange per waypoint covers every run of the batch
         return self.buf[w * n:(w + 1) * n]
 
     def end(self):
         return self.ctx.gmm_end()
+
+    def probabilities(self):
+        return self.ctx.batch_probabilities()
 
     def mc_local(self):
         return self.torch.tensor([self.ctx.mc_run_local()], dtype=self.torch.int64, device="cuda")

@@ -151,6 +151,40 @@ def test_gmm_variants_agree(ctx, pocs, plan, env):
     assert ctx.gmm_end() == base
 
 
+def test_batch_equals_consecutive_single_runs(ctx, plan, env):
+    """R estimations advanced in lockstep (one launch per waypoint for all of them) must give,
+    bit for bit, what R consecutive single runs give."""
+    ctx.configure(plan, env, K=3, N=5001, seed=17)
+    seq, seq_probs = [], []
+    for _ in range(5):
+        seq.append(ctx.run_gmm_estimation())
+        seq_probs.append(ctx.waypoint_probabilities().copy())
+    m0 = None
+    ctx.set_seed(17)
+    ctx.run_gmm_estimation()
+    m0 = ctx.moments(40, 3).copy()
+    ctx.set_seed(17)
+    ctx.set_batch(5)
+    try:
+        p0 = ctx.run_gmm_estimation()
+        assert p0 == seq[0] and list(ctx.batch_probabilities()) == seq
+        assert np.array_equal(ctx.waypoint_probabilities(), seq_probs[0])
+        assert np.array_equal(ctx.moments(40, 3), m0)
+        xyz, flags = ctx.gmm_samples(5001)                      # run 0's last waypoint
+        assert len(flags) == 5001
+        ctx.set_seed(17)
+        ctx.gmm_begin()                                          # the sharded protocol, batched
+        assert ctx.gmm_moments_len() == 5 * 33
+        for w in range(56):
+            ctx.gmm_step_local(w)
+        assert ctx.gmm_end() == seq[0] and list(ctx.batch_probabilities()) == seq
+        assert ctx.run_gmm_estimation() != seq[0]                # the next batch redraws
+    finally:
+        ctx.set_batch(1)
+    ctx.set_seed(17)
+    assert ctx.run_gmm_estimation() == seq[0]
+
+
 def test_runs_redraw_and_seed_rewinds(ctx, plan, env):
     ctx.configure(plan, env, K=3, N=4000, seed=5)
     a, b = ctx.run_gmm_estimation(), ctx.run_gmm_estimation()
