@@ -94,30 +94,59 @@ def main():
     env = pocs_amd.load_env()
     N = n_local * world
 
-    batch = max(1, min(args.batch, args.steps)) if path == "gmm" else 1
-    rem = args.steps % batch
+    # K steps are issued as `ncalls` calls of nearly equal batch: `n_hi` calls of b_hi = b_lo + 1
+    # runs and the rest of b_lo runs.
+    maxb = max(1, args.batch) if path == "gmm" else 1
+    ncalls = (args.steps + maxb - 1) // maxb
+    b_lo, n_hi = divmod(args.steps, ncalls)
+    b_hi = b_lo + 1 if n_hi else b_lo
+    batch = b_hi
+    chunks = [b_hi] * (n_hi if n_hi else ncalls) + ([b_lo] * (ncalls - n_hi) if n_hi else [])
 
-    def make(b, seed):
+    def make(b, seed, stream=None):
         c = pocs_amd.Context(local)
         c.configure(plan, env, K=K, N=N, seed=seed)
-        if sharded:     # one rank per GPU: launches on torch's stream, moments in a torch tensor
-            return c, par.GpuEngine(c, W, K, N, rank=rank, world=world, per_rank=n_local, batch=b)
+        if sharded:     # one rank per GPU: launches on a torch stream, moments in a torch tensor
+            return c, par.GpuEngine(c, W, K, N, rank=rank, world=world, per_rank=n_local, batch=b, stream=stream)
         c.set_batch(b)
         c.set_shard(0, n_local)
         return c, None
 
-    ctx, engine = make(batch, 0x5EED0001)
-    ctx_rem, engine_rem = make(rem, 0x5EED0002) if rem else (None, None)
+    if not sharded:
+        # one GPU: each distinct batch size has its own context (and its own captured hipGraph)
+        made = [make(b_hi, 0x5EED0001)]
+        if b_lo != b_hi and b_lo in chunks:
+            made.append(make(b_lo, 0x5EED0002))
+        ctx = made[0][0]
+        engines = []
 
-    def call(c, e):
-        """One call = `batch` steps (GMM) or one step (MC)."""
-        if path == "gmm":
-            if not sharded:
-                return c.run_gmm_estimation()            # the whole batch replayed from one hipGraph
-            return par.run_gmm_sharded(e, dist)          # per waypoint: step_local + all_reduce(batch*11K f64)
-        if not sharded:
-            return c.run_simulation()
-        return par.run_mc_sharded(e, N, dist)            # one all_reduce of the hit count
+        def run_steps(sizes):
+            p = 0.0
+            for b in sizes:
+                c = made[0][0] if b == b_hi else made[1][0]
+                p = c.run_gmm_estimation() if path == "gmm" else c.run_simulation()
+            return p
+    else:
+        # one rank per GPU: two engines on two streams take the calls in turn, so one engine's
+        # kernel runs while the other's moments are in the all-reduce (parallel.run_gmm_pipelined)
+        n_eng = 2 if (path == "gmm" and len(chunks) >= 2) else 1
+        made = [make(b_hi, 0x5EED0001 + i, torch.cuda.Stream() if n_eng > 1 else None) for i in range(n_eng)]
+        ctx = made[0][0]
+        engines = [e for _, e in made]
+
+        def run_steps(sizes):
+            p = 0.0
+            if path != "gmm":
+                for _ in sizes:
+                    p = par.run_mc_sharded(engines[0], N, dist)      # one all_reduce of the hit count
+                return p
+            for i in range(0, len(sizes), n_eng):
+                group = sizes[i:i + n_eng]
+                for e, b in zip(engines, group):
+                    if e.batch != b:
+                        e.set_batch(b)
+                p = par.run_gmm_pipelined(engines[:len(group)], dist)[0]
+            return p
 
     def fence():
         torch.cuda.synchronize()
@@ -125,17 +154,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range((args.warmup + batch - 1) // batch):      # >= W untimed steps
-        call(ctx, engine)
-    if ctx_rem is not None:
-        call(ctx_rem, engine_rem)
+    run_steps([b_hi] * max(1, (args.warmup + batch - 1) // batch) + ([b_lo] if b_lo != b_hi else []))   # >= W untimed steps
     fence()
     t0 = time.perf_counter()
-    prob = 0.0
-    for _ in range(args.steps // batch):
-        prob = call(ctx, engine)
-    if ctx_rem is not None:
-        prob = call(ctx_rem, engine_rem)
+    prob = run_steps(chunks)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -149,8 +171,16 @@ def main():
     # the launch stream (eager launches; not part of `value`)
     ctx.set_option(pocs_amd.OPT_PROFILE, 1)
     ms_tot, n_launch = 0.0, 0
-    for _ in range(max(1, min(args.steps // batch, 3))):
-        call(ctx, engine)
+    for _ in range(max(1, min(len(chunks), 3))):
+        if engines:
+            if engines[0].batch != b_hi:
+                engines[0].set_batch(b_hi)
+            if path == "gmm":
+                par.run_gmm_pipelined(engines[:1], dist)
+            else:
+                par.run_mc_sharded(engines[0], N, dist)
+        else:
+            run_steps([b_hi])
         ms, n = ctx.kernel_time()
         ms_tot += ms
         n_launch += n
@@ -183,15 +213,15 @@ def main():
             "config": {"workload": "%s: %s path, %s plan (%d waypoints), %d samples per GPU per run, K=%d, pr2test2 walls, PR2 0.668 m square footprint"
                                    % (args.workload, path.upper(), "bundled trajectory.dat/odometry.dat" if W == 56 else "resampled", W, n_local, K),
                        "waypoints": W, "samples_per_gpu": n_local, "components": K, "probability": prob,
-                       "runs_per_launch": batch},
+                       "runs_per_launch": batch, "calls": chunks,
+                       "engines_in_flight": len(engines) if engines else 1},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(plan, env, K, W, path, args.cpu_evals)
         print(json.dumps(out))
-    for c in (ctx, ctx_rem):
-        if c is not None:
-            c.close()
+    for c, _ in made:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -152,7 +152,7 @@ int grid_for(long long count, int runs = 1) {
   }
   const int one = grid_blocks(count, POCS_GMM_BLOCK, 1);
   if (runs <= 1) return one;
-  int per = ((target ? target : 256) + runs - 1) / runs;      // 256 = one 8-wave block per CU in all
+  int per = (target ? target : 256) / runs;      // floor: never more than one 8-wave block per CU in all
   if (per < 8) per = 8;
   return per < one ? per : one;
 }

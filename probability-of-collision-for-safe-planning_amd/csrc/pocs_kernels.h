@@ -7,7 +7,9 @@
 #include "pocs_model.h"
 
 #define POCS_BLOCK 256        // MC kernels
+#ifndef POCS_GMM_BLOCK
 #define POCS_GMM_BLOCK 512    // k_gmm_step: 8 waves, one block per CU -> 256 partial rows
+#endif
 #define POCS_MAX_BLOCKS 2048
 // chain record (doubles), one per step i < W-1:
 //   [0..2] applied control   [3..5] diag of M   [6..8] the noisy control actually driven (MC)

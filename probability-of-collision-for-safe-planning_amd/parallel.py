@@ -45,6 +45,27 @@ def run_gmm_sharded(engine, dist=None):
     return engine.end()
 
 
+def run_gmm_pipelined(engines, dist):
+    """Two (or more) engines, each with its own batch of runs and its own stream, advanced waypoint
+    by waypoint in turn: while one engine's moments are in the all-reduce (and its next launch
+    waits for them), the other engine's kernel has the GPU.  Collectives are issued from this one
+    thread in the same order on every rank.  Returns the list of per-engine probabilities."""
+    for e in engines:
+        with e.stream_ctx():
+            e.begin()
+    for w in range(engines[0].W):
+        for e in engines:
+            with e.stream_ctx():
+                e.step_local(w)
+                if dist is not None:
+                    dist.all_reduce(e.moments(w))
+    out = []
+    for e in engines:
+        with e.stream_ctx():
+            out.append(e.end())
+    return out
+
+
 def run_mc_sharded(engine, n_total, dist=None):
     """engine: mc_local() -> tensor [1] int64 with the shard's collided count."""
     cnt = engine.mc_local()
@@ -57,18 +78,30 @@ class GpuEngine:
     """A libpocs context bound to this rank's GPU, torch's current stream and a torch-owned
     moments buffer (so all_reduce can take views of it)."""
 
-    def __init__(self, ctx, W, K, n_total, rank=0, world=1, per_rank=None, batch=1):
+    def __init__(self, ctx, W, K, n_total, rank=0, world=1, per_rank=None, batch=1, stream=None):
         import torch
         self.ctx, self.W, self.K, self.torch = ctx, W, K, torch
+        self.stream = stream                   # a torch.cuda.Stream of its own (pipelined engines) or None
+        self.max_batch = batch
         self.batch = batch                     # independent runs advanced in lockstep (pocs_set_batch)
         ctx.set_batch(batch)
         first, count = (rank * per_rank, per_rank) if per_rank else shard_range(n_total, rank, world)
         ctx.set_shard(first, count)
         self.count = count
-        # launch on torch's current stream so kernels and collectives are ordered without host syncs
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        # launch on a torch stream so kernels and collectives are ordered without host syncs
+        ctx.set_stream((stream or torch.cuda.current_stream()).cuda_stream)
         self.buf = torch.zeros(W * batch * K * 11, dtype=torch.float64, device="cuda")   # [W][batch][K*11]
         ctx.gmm_bind_moments(self.buf.data_ptr(), self.buf.numel())
+
+    def stream_ctx(self):
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def set_batch(self, b):
+        """Fewer runs than the engine was sized for (last, partial call of a sequence)."""
+        assert 1 <= b <= self.max_batch
+        self.ctx.set_batch(b)
+        self.batch = b
 
     def begin(self):
         self.ctx.gmm_begin()
