@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8,
                     help="independent runs (steps) advanced in lockstep per call (pocs_set_batch)")
     ap.add_argument("--samples", type=int, default=0, help="override samples per GPU (experiments only)")
+    ap.add_argument("--mc-fused", action="store_true",
+                    help="MC workloads: whole roll-out in registers (k_mc_fused, ~0 B/eval) instead of streaming")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=float, default=6.0e7, help="size of the CPU baseline sample")
     args = ap.parse_args()
@@ -106,6 +108,8 @@ def main():
     def make(b, seed, stream=None):
         c = pocs_amd.Context(local)
         c.configure(plan, env, K=K, N=N, seed=seed)
+        if args.mc_fused:
+            c.set_option(pocs_amd.OPT_MC_FUSED, 1)
         if sharded:     # one rank per GPU: launches on a torch stream, moments in a torch tensor
             return c, par.GpuEngine(c, W, K, N, rank=rank, world=world, per_rank=n_local, batch=b, stream=stream)
         c.set_batch(b)
@@ -185,7 +189,7 @@ def main():
         ms_tot += ms
         n_launch += n
     ctx.set_option(pocs_amd.OPT_PROFILE, 0)
-    kern = "k_gmm_step" if path == "gmm" else "k_mc_step"
+    kern = "k_gmm_step" if path == "gmm" else ("k_mc_fused" if args.mc_fused else "k_mc_step")
     bpe = BYTES_PER_EVAL_GMM if path == "gmm" else BYTES_PER_EVAL_MC
     avg_ms = ms_tot / max(n_launch, 1)
     units = n_local * batch                   # evaluations one launch of the hot kernel processes
