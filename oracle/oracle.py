@@ -51,6 +51,8 @@ class Oracle:
         L.orc_run_gmm.restype = C.c_double
         L.orc_run_mc.restype = C.c_longlong
         L.orc_collides.restype = C.c_int
+        L.orc_log_unit53.restype = C.c_double
+        L.orc_log_unit53.argtypes = [C.c_uint64]
 
     # ---- primitives -------------------------------------------------------------------
     def philox(self, ctr, key):
@@ -71,6 +73,19 @@ class Oracle:
     def sincos_2pi_u32(self, w):
         s, c = C.c_double(), C.c_double()
         self.lib.orc_sincos_2pi_u32(C.c_uint32(w), C.byref(s), C.byref(c))
+        return s.value, c.value
+
+    def log_unit53(self, m):
+        return self.lib.orc_log_unit53(C.c_uint64(m))
+
+    def sincos_tab(self, x):
+        s, c = C.c_double(), C.c_double()
+        self.lib.orc_sincos_tab(C.c_double(x), C.byref(s), C.byref(c))
+        return s.value, c.value
+
+    def sincos_2pi_u32_tab(self, w):
+        s, c = C.c_double(), C.c_double()
+        self.lib.orc_sincos_2pi_u32_tab(C.c_uint32(w), C.byref(s), C.byref(c))
         return s.value, c.value
 
     def normal3(self, seed, index, waypoint, stream):

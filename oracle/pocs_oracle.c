@@ -185,6 +185,92 @@ void orc_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stre
   *spare = a[3];
 }
 
+/* ---- table-driven forms (hot path: mixture samples, footprint heading) ------------------------
+ * lg[i] = {1/c_i rounded, -log(that)}, c_i = 1 + (i + 1/2)/128; sc[s] = {cos, sin} of the centre of
+ * sector s of 64.  Built from the functions above, on first use. */
+static double tab_lg[128][2], tab_sc[64][2];
+static int tab_ready = 0;
+static void tables(void) {
+  if (tab_ready) return;
+  for (int i = 0; i < 128; ++i) {
+    double c = 1.0 + ((double)i + 0.5) / 128.0;
+    tab_lg[i][0] = 1.0 / c;
+    tab_lg[i][1] = -orc_log(tab_lg[i][0]);
+  }
+  for (int s = 0; s < 64; ++s) {
+    double sn, cs;
+    orc_sincos_2pi_u32(((uint32_t)s << 26) + (1u << 25), &sn, &cs);
+    tab_sc[s][0] = cs; tab_sc[s][1] = sn;
+  }
+  tab_ready = 1;
+}
+
+double orc_log_unit53(uint64_t m) {   /* log(m 2^-53), 1 <= m <= 2^53 */
+  tables();
+  double x = (double)m;
+  uint64_t bits;
+  memcpy(&bits, &x, 8);
+  int e = (int)(bits >> 52) - 1023;
+  int i = (int)((bits >> 45) & 127);
+  bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+  double t;
+  memcpy(&t, &bits, 8);
+  double r = fma(t, tab_lg[i][0], -1.0);
+  static const double co[6] = {-0.5, 1.0 / 3.0, -1.0 / 4.0, 1.0 / 5.0, -1.0 / 6.0, 1.0 / 7.0};
+  double p = co[5];
+  for (int k = 4; k >= 0; --k) p = fma(r, p, co[k]);
+  double l1p = fma(r * r, p, r);
+  double dk = (double)(e - 53);
+  return fma(dk, 6.93147180369123816490e-01, tab_lg[i][1]) + fma(dk, 1.90821492927058770002e-10, l1p);
+}
+
+static void sincos_small(double d, double* sd, double* cd) {
+  double z = d * d;
+  double ps = fma(z, -1.0 / 5040.0, 1.0 / 120.0);
+  ps = fma(z, ps, -1.0 / 6.0);
+  *sd = fma(d * z, ps, d);
+  double pc = fma(z, 1.0 / 40320.0, -1.0 / 720.0);
+  pc = fma(z, pc, 1.0 / 24.0);
+  pc = fma(z, pc, -0.5);
+  *cd = fma(z, pc, 1.0);
+}
+
+void orc_sincos_2pi_u32_tab(uint32_t w, double* s, double* c) {
+  tables();
+  int sec = (int)(w >> 26);
+  int f = (int)(w & 0x03ffffffu) - (1 << 25);
+  double d = (double)f * ((1.0 / 67108864.0) * 9.81747704246810387019e-02);
+  double sd, cd;
+  sincos_small(d, &sd, &cd);
+  double C = tab_sc[sec][0], S = tab_sc[sec][1];
+  *s = fma(S, cd, C * sd);
+  *c = fma(C, cd, -(S * sd));
+}
+
+void orc_sincos_tab(double x, double* s, double* c) {
+  tables();
+  double fn = floor(x * 1.01859163578813017e+01);
+  int n = (int)fn;
+  double d = x - fn * 9.81747704208828509e-02;
+  d = d - fn * 3.79818781643997874e-12;
+  d = d - fn * 1.26391640549746914e-22;
+  double sd, cd;
+  sincos_small(d - 4.90873852123405193510e-02, &sd, &cd);
+  int sec = n & 63;
+  double C = tab_sc[sec][0], S = tab_sc[sec][1];
+  *s = fma(S, cd, C * sd);
+  *c = fma(C, cd, -(S * sd));
+}
+
+void orc_normal_pair_tab(uint32_t w0, uint32_t w1, uint32_t w2, double* n0, double* n1) {
+  uint64_t a = (((uint64_t)w1 << 32) | w0) >> 11;
+  double radius = sqrt(-2.0 * orc_log_unit53(a + 1));
+  double s, c;
+  orc_sincos_2pi_u32_tab(w2, &s, &c);
+  *n0 = radius * c;
+  *n1 = radius * s;
+}
+
 /* mixture samples come in pairs (2j, 2j+1) that share three draws keyed by the pair index j:
  * slot 0 -> z0,z1 of 2j (+ spare of 2j); slot 1 -> z2 of 2j, z0 of 2j+1 (+ spare of 2j+1);
  * slot 2 -> z1,z2 of 2j+1.  This returns the normals and spare word of ONE sample. */
@@ -196,15 +282,15 @@ void orc_sample_normals(uint64_t seed, uint64_t sample, uint32_t waypoint, uint3
   draw(seed, pair, waypoint, stream, 1, w1);
   if ((sample & 1) == 0) {
     draw(seed, pair, waypoint, stream, 0, w0);
-    orc_normal_pair(w0[0], w0[1], w0[2], &z[0], &z[1]);
-    orc_normal_pair(w1[0], w1[1], w1[2], &a, &b);
+    orc_normal_pair_tab(w0[0], w0[1], w0[2], &z[0], &z[1]);
+    orc_normal_pair_tab(w1[0], w1[1], w1[2], &a, &b);
     z[2] = a;
     *spare = w0[3];
   } else {
     draw(seed, pair, waypoint, stream, 2, w2);
-    orc_normal_pair(w1[0], w1[1], w1[2], &a, &b);
+    orc_normal_pair_tab(w1[0], w1[1], w1[2], &a, &b);
     z[0] = b;
-    orc_normal_pair(w2[0], w2[1], w2[2], &z[1], &z[2]);
+    orc_normal_pair_tab(w2[0], w2[1], w2[2], &z[1], &z[2]);
     *spare = w1[3];
   }
 }
@@ -356,7 +442,7 @@ void orc_normalise_l1(const double* in, int n, double* out) {
 /* ------------------------------------------------------------------------------------------ */
 int orc_collides(double x, double y, double th, const double fp[4], const double* boxes, int M) {
   double s, c;
-  orc_sincos(th, &s, &c);
+  orc_sincos_tab(th, &s, &c);
   double px = x + fma(c, fp[0], -(s * fp[1]));
   double py = y + fma(s, fp[0], c * fp[1]);
   double rx = fp[2], ry = fp[3];

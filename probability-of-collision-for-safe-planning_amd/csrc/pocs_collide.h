@@ -51,9 +51,9 @@ POCS_HD bool pocs_box_hit(double px, double py, double sn, double cs, double rx,
 
 // checkCollision for one pose: true if the footprint touches any of the M obstacles.
 POCS_HD bool pocs_pose_collides(double x, double y, double th, const pocs_footprint* fp,
-                                const double* obs, int M) {
+                                const double* obs, int M, const pocs_tables* T) {
   double sn, cs;
-  pocs_sincos(th, &sn, &cs);
+  pocs_sincos_tab(th, T, &sn, &cs);
   const double px = x + fma(cs, fp->dx, -(sn * fp->dy));
   const double py = y + fma(sn, fp->dx, cs * fp->dy);
   bool hit = false;

@@ -21,7 +21,7 @@
 #include "../../include/pocs.h"
 #include "pocs_kernels.h"
 
-#define POCS_VERSION_STRING "pocs-mi355x 0.1 (gfx950; numerics v2)"
+#define POCS_VERSION_STRING "pocs-mi355x 0.1 (gfx950; numerics v3)"
 
 namespace {
 
@@ -63,7 +63,7 @@ struct pocs_ctx {
 
   // ---- device state ----
   DevBuf d_env, d_sensor, d_hdr, d_chain, d_state, d_param, d_moments, d_partial;
-  DevBuf d_sx, d_sy, d_st, d_flags, d_px, d_py, d_pt, d_hits, d_total, d_ticket;
+  DevBuf d_sx, d_sy, d_st, d_flags, d_px, d_py, d_pt, d_hits, d_total, d_ticket, d_tables;
   double* ext_moments = nullptr;         // caller-owned moments buffer (multi-GPU), or null
   long long ext_moments_len = 0;
   void* h_pin = nullptr;                 // pinned staging: hdr | chain | state0 | moments | total
@@ -251,6 +251,12 @@ int check_common(pocs_ctx* c) {
 }
 
 int upload_static(pocs_ctx* c) {
+  if (!c->d_tables.p) {                       // log / sector tables of the numerics spec, once
+    pocs_tables T;
+    pocs_tables_init(&T);
+    if (int r = ensure(c, c->d_tables, sizeof T)) return r;
+    HIPCHK(c, hipMemcpy(c->d_tables.p, &T, sizeof T, hipMemcpyHostToDevice));
+  }
   if (c->env_dirty) {
     pocs_env_dev env;
     memset(&env, 0, sizeof env);
@@ -403,6 +409,7 @@ void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long
   memset(a, 0, sizeof *a);
   a->hdr = (const pocs_run_header*)c->d_hdr.p;
   a->env = (const pocs_env_dev*)c->d_env.p;
+  a->tables = (const pocs_tables*)c->d_tables.p;
   a->chain = (const double*)c->d_chain.p;
   a->sensor = (const pocs_sensor*)c->d_sensor.p;
   a->state = (double*)c->d_state.p;
@@ -539,6 +546,7 @@ int enqueue_mc_all(pocs_ctx* c, long long first, long long count, bool prof) {
   pocs_mc_launch a;
   a.hdr = (const pocs_run_header*)c->d_hdr.p;
   a.env = (const pocs_env_dev*)c->d_env.p;
+  a.tables = (const pocs_tables*)c->d_tables.p;
   a.chain = (const double*)c->d_chain.p;
   a.x = (double*)c->d_px.p; a.y = (double*)c->d_py.p; a.th = (double*)c->d_pt.p;
   a.hits = (uint32_t*)c->d_hits.p;
@@ -716,7 +724,7 @@ void pocs_destroy(pocs_ctx* c) {
     for (hipEvent_t e : c->events) hipEventDestroy(e);
     DevBuf* all[] = {&c->d_env, &c->d_sensor, &c->d_hdr, &c->d_chain, &c->d_state, &c->d_param,
                      &c->d_moments, &c->d_partial, &c->d_sx, &c->d_sy, &c->d_st, &c->d_flags,
-                     &c->d_px, &c->d_py, &c->d_pt, &c->d_hits, &c->d_total, &c->d_ticket};
+                     &c->d_px, &c->d_py, &c->d_pt, &c->d_hits, &c->d_total, &c->d_ticket, &c->d_tables};
     for (DevBuf* b : all) if (b->p) hipFree(b->p);
     if (c->h_pin) hipHostFree(c->h_pin);
     hipStreamDestroy(c->own_stream);

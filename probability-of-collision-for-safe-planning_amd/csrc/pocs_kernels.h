@@ -35,6 +35,7 @@ struct pocs_run_header {         // per-run scalars read by every kernel (so a c
 struct pocs_gmm_launch {
   const pocs_run_header* hdr;    // [nruns] per-run seeds
   const pocs_env_dev* env;       // obstacle table (records only; M and the footprint travel below)
+  const pocs_tables* tables;     // log / sector tables (pocs_math.h), staged to LDS
   const double* chain;           // [nruns][W-1][POCS_CHAIN_STRIDE]
   const pocs_sensor* sensor;
   double* state;                 // [nruns][W][K*POCS_STATE_STRIDE]  mixture sampled at each waypoint
@@ -59,6 +60,7 @@ struct pocs_gmm_launch {
 struct pocs_mc_launch {
   const pocs_run_header* hdr;
   const pocs_env_dev* env;
+  const pocs_tables* tables;
   const double* chain;                 // noisy control of step s at chain[s*STRIDE+6..8]
   double* x; double* y; double* th;    // SoA particle state of this shard
   uint32_t* hits;                      // particlecollisions

@@ -61,6 +61,13 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
          (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
 }
 
+// Stage the log / sector tables (3 KB) into LDS.
+__device__ __forceinline__ void stage_tables(const pocs_tables* __restrict__ g, pocs_tables* s_tab) {
+  const double* src = reinterpret_cast<const double*>(g);
+  double* dst = reinterpret_cast<double*>(s_tab);
+  for (int j = threadIdx.x; j < (int)(sizeof(pocs_tables) / sizeof(double)); j += blockDim.x) dst[j] = src[j];
+}
+
 // Stage the collision world into LDS.  s_obs must hold POCS_MAX_OBSTACLES*POCS_OBS_STRIDE doubles.
 __device__ __forceinline__ void stage_env(const pocs_env_dev* __restrict__ env, double* s_obs,
                                           pocs_footprint* s_fp, int* s_M) {
@@ -138,6 +145,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   __shared__ double s_part[POCS_GMM_BLOCK];
   __shared__ double s_adv[POCS_ADV_SCRATCH(K)];
   __shared__ double s_keep[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
+  __shared__ pocs_tables s_tab;
   __shared__ int s_nkeep;
   __shared__ int s_last;
 
@@ -147,7 +155,8 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   const int M = a.M;
   const pocs_footprint fp = a.fp;
 
-  // ---- head: stage the obstacle table and this waypoint's sampler parameters in LDS
+  // ---- head: stage the tables, the obstacle table and this waypoint's sampler parameters in LDS
+  stage_tables(a.tables, &s_tab);
   for (int j = tid; j < M * POCS_OBS_STRIDE; j += POCS_GMM_BLOCK) s_obs[j] = a.env->obs[j];
   for (int j = tid; j < K * POCS_PARAM_STRIDE; j += POCS_GMM_BLOCK)
     s_par[j] = a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j];
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
       zz[0][0] = (double)A.x * 0x1p-32; zz[0][1] = (double)A.y * 0x1p-32; zz[0][2] = (double)A.z * 0x1p-32; spare[0] = A.w;
       zz[1][0] = (double)B.x * 0x1p-32; zz[1][1] = (double)B.y * 0x1p-32; zz[1][2] = (double)(B.z ^ Cc.x ^ Cc.y ^ Cc.z) * 0x1p-32; spare[1] = B.w; }
 #else
-    pocs_normal3_pair(seed, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, zz[0], zz[1], &spare[0], &spare[1]);
+    pocs_normal3_pair(seed, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, &s_tab, zz[0], zz[1], &spare[0], &spare[1]);
 #endif
     const long long i0 = 2 * lp;
     const bool two = (i0 + 1) < a.count;          // false only for the last sample of an odd shard
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
 #if defined(POCS_ABLATE_COLLIDE)
       const bool hit = x > t;
 #else
-      const bool hit = pocs_pose_collides(x, y, t, &fp, s_keep, nkeep);
+      const bool hit = pocs_pose_collides(x, y, t, &fp, s_keep, nkeep, &s_tab);
 #endif
       xs[h] = x; ys[h] = y; ts[h] = t; hits[h] = hit;
       // T1 sums: acc_k += ind_k * (x, y, t, xx, xy, xt, yy, yt, tt) with ind_k = 1.0 for the
@@ -342,7 +351,9 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_init(pocs_mc_launch a) {
   __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
   __shared__ pocs_footprint s_fp;
   __shared__ int s_M;
+  __shared__ pocs_tables s_tab;
   stage_env(a.env, s_obs, &s_fp, &s_M);
+  stage_tables(a.tables, &s_tab);
   __syncthreads();
   const uint64_t seed = a.hdr->seed;
   const pocs_footprint fp = s_fp;
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_init(pocs_mc_launch a) {
     const double y = fma(a.L0[2], z[1], fma(a.L0[1], z[0], a.mu0[1]));
     const double t = fma(a.L0[5], z[2], fma(a.L0[4], z[1], fma(a.L0[3], z[0], a.mu0[2])));
     a.x[i] = x; a.y[i] = y; a.th[i] = t;
-    a.hits[i] = pocs_pose_collides(x, y, t, &fp, s_obs, M) ? 1u : 0u;
+    a.hits[i] = pocs_pose_collides(x, y, t, &fp, s_obs, M, &s_tab) ? 1u : 0u;
   }
 }
 
@@ -364,7 +375,9 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_step(pocs_mc_launch a) {
   __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
   __shared__ pocs_footprint s_fp;
   __shared__ int s_M;
+  __shared__ pocs_tables s_tab;
   stage_env(a.env, s_obs, &s_fp, &s_M);
+  stage_tables(a.tables, &s_tab);
   __syncthreads();
   const pocs_footprint fp = s_fp;
   const int M = s_M;
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_step(pocs_mc_launch a) {
     const double ny = fma(u1, sn, y);
     const double nt = pocs_wrap_angle(t + u0 + u2);
     a.x[i] = nx; a.y[i] = ny; a.th[i] = nt;
-    if (pocs_pose_collides(nx, ny, nt, &fp, s_obs, M)) a.hits[i] += 1u;
+    if (pocs_pose_collides(nx, ny, nt, &fp, s_obs, M, &s_tab)) a.hits[i] += 1u;
   }
 }
 
@@ -387,7 +400,9 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_fused(pocs_mc_launch a) {
   __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
   __shared__ pocs_footprint s_fp;
   __shared__ int s_M;
+  __shared__ pocs_tables s_tab;
   stage_env(a.env, s_obs, &s_fp, &s_M);
+  stage_tables(a.tables, &s_tab);
   __syncthreads();
   const uint64_t seed = a.hdr->seed;
   const pocs_footprint fp = s_fp;
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_fused(pocs_mc_launch a) {
     double x = fma(a.L0[0], z[0], a.mu0[0]);
     double y = fma(a.L0[2], z[1], fma(a.L0[1], z[0], a.mu0[1]));
     double t = fma(a.L0[5], z[2], fma(a.L0[4], z[1], fma(a.L0[3], z[0], a.mu0[2])));
-    unsigned h = pocs_pose_collides(x, y, t, &fp, s_obs, M) ? 1u : 0u;
+    unsigned h = pocs_pose_collides(x, y, t, &fp, s_obs, M, &s_tab) ? 1u : 0u;
     for (int s = 0; s < a.step; ++s) {
       const double* u = a.chain + (size_t)s * POCS_CHAIN_STRIDE + 6;   // wave-uniform
       const double u0 = u[0], u1 = u[1], u2 = u[2];
@@ -409,7 +424,7 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_fused(pocs_mc_launch a) {
       x = fma(u1, cs, x);
       y = fma(u1, sn, y);
       t = pocs_wrap_angle(t + u0 + u2);
-      h += pocs_pose_collides(x, y, t, &fp, s_obs, M) ? 1u : 0u;
+      h += pocs_pose_collides(x, y, t, &fp, s_obs, M, &s_tab) ? 1u : 0u;
     }
     a.x[i] = x; a.y[i] = y; a.th[i] = t;
     a.hits[i] = h;

@@ -42,6 +42,37 @@ def test_normal3_bitwise(hh, orc):
             assert list(z) == want_z and sp.value == want_sp
 
 
+def test_table_functions_bitwise_and_accurate(hh, orc):
+    """The table-driven log / sincos of the hot path: product == oracle bit for bit, and both
+    within ~1 ulp of libm."""
+    hh.hh_log_unit53.restype = C.c_double
+    hh.hh_log_unit53.argtypes = [C.c_uint64]
+    rng = np.random.default_rng(21)
+    ms = [1, 2, 3, 2 ** 53, 2 ** 53 - 1, 2 ** 52, 2 ** 52 + 1] + [int(v) for v in rng.integers(1, 2 ** 53, 20000)] + \
+         [int(v) for v in rng.integers(1, 2 ** 20, 2000)]
+    worst = 0.0
+    for m in ms:
+        got = hh.hh_log_unit53(m)
+        assert got == orc.log_unit53(m)
+        want = math.log(m * 2.0 ** -53)            # m * 2^-53 is exact in binary64
+        # absolute accuracy (what the radius sqrt(-2 log u) needs); near u = 1 the table form
+        # cancels, so its RELATIVE error there is larger than the polynomial form's -- harmless
+        worst = max(worst, abs(got - want) / max(abs(want), 1.0))
+    assert worst < 3e-16, worst
+    assert abs(hh.hh_log_unit53(2 ** 53)) < 2e-16
+    s, c = C.c_double(), C.c_double()
+    for x in np.concatenate([rng.uniform(-20, 20, 8000), rng.uniform(-1e4, 1e4, 1000), [0.0, -0.0, 6.283185307179586, 1.5707963267948966]]):
+        hh.hh_sincos_tab(C.c_double(x), C.byref(s), C.byref(c))
+        assert (s.value, c.value) == orc.sincos_tab(float(x))
+        assert abs(s.value - math.sin(x)) < 4e-16 * max(1.0, abs(x) / 10) and abs(c.value - math.cos(x)) < 4e-16 * max(1.0, abs(x) / 10)
+    for w in np.concatenate([rng.integers(0, 2 ** 32, 8000), [0, 2 ** 26 - 1, 2 ** 26, 2 ** 25, 2 ** 32 - 1, 2 ** 31]]):
+        hh.hh_sincos_2pi_u32_tab(C.c_uint32(int(w)), C.byref(s), C.byref(c))
+        assert (s.value, c.value) == orc.sincos_2pi_u32_tab(int(w))
+        ws, wc = orc.sincos_2pi_u32(int(w))              # the polynomial version, itself within 2.3e-16 of libm
+        assert abs(s.value - ws) < 4e-16 and abs(c.value - wc) < 4e-16
+        assert abs(s.value ** 2 + c.value ** 2 - 1.0) < 6e-16
+
+
 def test_sample_pairs_bitwise(hh, orc):
     """Mixture samples 2j and 2j+1 share three draws keyed by the pair index j."""
     za, zb = (C.c_double * 3)(), (C.c_double * 3)()
