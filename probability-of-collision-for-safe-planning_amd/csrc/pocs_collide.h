@@ -42,10 +42,13 @@ POCS_HD bool pocs_box_hit(double px, double py, double sn, double cs, double rx,
   const double d2 = fma(dy, cs, -(dx * sn));
   const double e1 = fma(dx, ax, dy * ay);                         // d in the obstacle frame
   const double e2 = fma(dy, ax, -(dx * ay));
-  const bool sep = (fabs(d1) > rx + fma(hx, acr, hy * asr)) |
-                   (fabs(d2) > ry + fma(hx, asr, hy * acr)) |
-                   (fabs(e1) > hx + fma(rx, acr, ry * asr)) |
-                   (fabs(e2) > hy + fma(rx, asr, ry * acr));
+  // separated along any of the four face normals: a > b  <=>  a - b > 0 exactly in IEEE
+  // arithmetic (gradual underflow), so the four tests fold into one compare of the largest margin
+  const double m1 = fabs(d1) - (rx + fma(hx, acr, hy * asr));
+  const double m2 = fabs(d2) - (ry + fma(hx, asr, hy * acr));
+  const double m3 = fabs(e1) - (hx + fma(rx, acr, ry * asr));
+  const double m4 = fabs(e2) - (hy + fma(rx, asr, ry * acr));
+  const bool sep = fmax(fmax(m1, m2), fmax(m3, m4)) > 0.0;
   return !sep;
 }
 

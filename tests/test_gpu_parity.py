@@ -260,6 +260,53 @@ def test_shards_partition_the_work(ctx, orc, plan, env):
     assert n0 + n1 == ctx.mc_run_local() == orc.run_mc(cfg, 21, N)[0]
 
 
+@pytest.mark.parametrize("K,N", [(3, 2), (3, 3), (8, 9), (2, 1), (8, 40)])
+def test_degenerate_mixtures_match_oracle(ctx, orc, plan, env, K, N):
+    """Tiny N: components run out of survivors (< 2) or all samples collide -- cases the reference
+    leaves undefined; the build retires such components, on both sides alike."""
+    cfg = orc.config(plan, env, K=K)
+    for seed in (1, 2, 3):
+        ctx.configure(plan, env, K=K, N=N, seed=seed)
+        p = ctx.run_gmm_estimation()
+        want = orc.run_gmm(cfg, seed, N)
+        assert np.array_equal(ctx.waypoint_probabilities(), want["probs"])
+        assert abs(p - want["prob"]) < 1e-15
+        got_alive = np.array([ctx.gmm_state(w, K)[3] for w in range(cfg.W)])
+        assert np.array_equal(got_alive, want["states"][:, :, 13])
+        assert np.array_equal(np.array([ctx.gmm_state(w, K)[2] for w in range(cfg.W)]), want["states"][:, :, 12])
+    assert not np.all(want["states"][:, :, 13] == 1.0)          # something did get retired
+
+
+def test_limits_of_the_boundary(ctx, pocs, orc, plan):
+    """Maximum table sizes: 64 obstacles, 32 landmarks; shortest plans W = 1, 2; an empty shard."""
+    rng = np.random.default_rng(8)
+    boxes = np.column_stack([rng.uniform(-3.5, 3.5, 64), rng.uniform(-1.7, 1.7, 64), rng.uniform(0.02, 0.15, 64),
+                             rng.uniform(0.02, 0.15, 64), rng.uniform(-3.2, 3.2, 64)])
+    env64 = dict(footprint=[0.02, 0.01, 0.3, 0.2], boxes=boxes)
+    lm = np.vstack([rng.uniform(-4, 4, 32), rng.uniform(-2, 2, 32)])
+    params = dict(pocs.DEFAULTS, landmarks=lm.tolist())
+    for W in (1, 2, 56):
+        pl = dict(traj=plan["traj"][:W], odom=plan["odom"][:max(W - 1, 0)])
+        cfg = orc.config(pl, env64, K=3, landmarks=lm)
+        ctx.configure(pl, env64, params=params, K=3, N=3000, seed=4)
+        p = ctx.run_gmm_estimation()
+        want = orc.run_gmm(cfg, 4, 3000, want_samples=True)
+        assert np.array_equal(ctx.gmm_samples(3000)[1], want["flags"]) and abs(p - want["prob"]) < 1e-12
+        ctx.set_seed(4)
+        assert ctx.run_simulation() == orc.run_mc(cfg, 4, 3000)[0] / 3000
+    with pytest.raises(pocs.PocsError):
+        ctx.set_env(dict(footprint=[0, 0, 0.3, 0.3], boxes=np.zeros((65, 5)) + 0.1))
+    with pytest.raises(pocs.PocsError):
+        ctx.set_landmarks(np.zeros((2, 33)))
+    # an empty shard contributes nothing and does not fault
+    ctx.configure(plan, env64, K=3, N=1000, seed=4)
+    ctx.set_shard(1000, 0)
+    assert ctx.mc_run_local() == 0
+    ctx.gmm_begin()
+    ctx.gmm_step_local(0)
+    ctx.set_shard()
+
+
 def test_text_channel_is_a_drop_in(ctx, pocs, orc, plan, env):
     """The exact command sequence of MCSimulation.py:154-207,238-245 over the text channel."""
     def l2s(v):
