@@ -1,18 +1,23 @@
 // pocs_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the hot path.
 //
-//   k_gmm_step      S1+C1+T1  one waypoint of truncateGMM (MCSimulator.h:570-642) in ONE launch:
-//                             head  a dedicated wave folds the previous waypoint's reduced moments
-//                                   into the mixture -- truncated mean/cov, weights (:597-629), the
-//                                   per-component EKF predict/update (:766-771, :804-812), Cholesky --
-//                                   while the sampling waves stage the obstacle table and generate
-//                                   their first normals;
+//   k_gmm_step      S1+C1+T1  one waypoint of truncateGMM (MCSimulator.h:570-642) in ONE launch, for
+//                             every run of a batch of independent estimations (blockIdx.y = run):
+//                             head  log/sector tables, obstacle table and this waypoint's sampler
+//                                   parameters -> LDS; exact culling of the obstacle table against
+//                                   the mixture's bounding box;
 //                             body  GM_Model::sampleNPoints (GM_Model.h:83-116) + checkMatrixCollisions
-//                                   (:241-253) + the moment sums (:592-611), fused: a sample is born,
-//                                   tested and folded into its component's (n, sum x, sum x x^T) in
-//                                   registers; pose and flag are streamed out once (24 B + 2 B);
-//                             tail  DPP wave reduction -> LDS -> one write-through partial row per
-//                                   block -> the last block to arrive adds the rows in a fixed order.
+//                                   (:241-253) + the moment sums (:592-611), fused, one PAIR of
+//                                   samples per thread-iteration: a sample is born, tested and folded
+//                                   into its component's (n, sum x, sum x x^T) in registers; pose
+//                                   and flag are streamed out once (24 B + 2 B);
+//                             tail  DPP row sums -> LDS -> one write-through partial row per block ->
+//                                   the last block to arrive adds the rows in a fixed order and (one
+//                                   GPU) advances the mixture to the next waypoint: truncated
+//                                   mean/cov, weights (:597-629), per-component EKF predict/update
+//                                   (:766-771, :804-812), Cholesky.
 //                             The waypoint loop never returns to the host.
+//   k_gmm_advance   T1 tail   the same mixture advance as its own launch (waypoint 0; after the
+//                             caller's all-reduce when the samples are sharded over GPUs).
 //   k_mc_init       P2+P3     initParticles (:287-297) + first checkParticleCollisions (:333-347)
 //   k_mc_step       P1+P3     moveParticles (:300-322) + checkParticleCollisions, one waypoint,
 //                             particles streamed through HBM (SoA): 24 B in, 24 B out, u32 RMW.
@@ -21,9 +26,9 @@
 //   k_mc_count      P3        getCollisionProportion (:324-330): |{hits > 0}|.
 //
 // Bound: these are FP64-VALU / HBM streaming kernels, no contraction => no MFMA.  Mixture
-// parameters and the obstacle table are staged in LDS once per block (all lanes read the same
-// obstacle record => LDS broadcast, no bank conflicts; the per-lane component lookup is a
-// 12-double row per lane).  Reductions are wave64 butterflies followed by one LDS pass and a
+// parameters, the obstacle table and the 3 KB of log/sector tables are staged in LDS once per
+// block (all lanes read the same obstacle record => LDS broadcast; the per-lane component and
+// table lookups are 16-byte reads).  Reductions are DPP row sums followed by one LDS pass and a
 // per-block partial row; partials are combined in a fixed order so results are bitwise
 // reproducible run to run (no float atomics).
 #include "pocs_kernels.h"

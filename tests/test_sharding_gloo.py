@@ -50,6 +50,10 @@ class OracleEngine:
         n, _, _ = self.orc.run_mc(self.cfg, self.seed, self.N, first=self.first, count=self.count)
         return torch.tensor([n], dtype=torch.int64)
 
+    def stream_ctx(self):                      # GpuEngine runs each engine on its own stream
+        import contextlib
+        return contextlib.nullcontext()
+
 
 def _worker(rank, world, port, N, K, seed, out):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "oracle"))
@@ -66,8 +70,11 @@ def _worker(rank, world, port, N, K, seed, out):
     eng = OracleEngine(orc, cfg, seed, N, first, count)
     p_gmm = par.run_gmm_sharded(eng, dist)
     p_mc = par.run_mc_sharded(eng, N, dist)
+    # two engines in flight (different seeds), advanced waypoint by waypoint in turn
+    eng2 = [OracleEngine(orc, cfg, seed + 1, N, first, count), OracleEngine(orc, cfg, seed + 2, N, first, count)]
+    p_pipe = par.run_gmm_pipelined(eng2, dist)
     if rank == 0:
-        np.save(out, np.array([p_gmm, p_mc]))
+        np.save(out, np.array([p_gmm, p_mc] + p_pipe))
     # every rank must hold the same reduced moments (no broadcast is ever needed)
     t = eng.buf.clone()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -81,11 +88,13 @@ def test_two_ranks_equal_one(tmp_path, orc, plan, env, N, K):
     out = tmp_path / "res.npy"
     port = 29600 + (os.getpid() % 300) + K
     mp.spawn(_worker, args=(2, port, N, K, seed, str(out)), nprocs=2, join=True)
-    p_gmm, p_mc = np.load(out)
+    p_gmm, p_mc, p_a, p_b = np.load(out)
     cfg = orc.config(plan, env, K=K)
     want = orc.run_gmm(cfg, seed, N)
     assert abs(p_gmm - want["prob"]) < 1e-12
     assert p_mc == orc.run_mc(cfg, seed, N)[0] / N
+    assert abs(p_a - orc.run_gmm(cfg, seed + 1, N)["prob"]) < 1e-12      # pipelined engines
+    assert abs(p_b - orc.run_gmm(cfg, seed + 2, N)["prob"]) < 1e-12
 
 
 def test_shard_range_partitions():
