@@ -110,6 +110,8 @@ def main():
         c.configure(plan, env, K=K, N=N, seed=seed)
         if args.mc_fused:
             c.set_option(pocs_amd.OPT_MC_FUSED, 1)
+        if os.environ.get("POCS_NO_STORE") == "1":       # tuning only: samples not written to HBM
+            c.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
         if sharded:     # one rank per GPU: launches on a torch stream, moments in a torch tensor
             return c, par.GpuEngine(c, W, K, N, rank=rank, world=world, per_rank=n_local, batch=b, stream=stream)
         c.set_batch(b)

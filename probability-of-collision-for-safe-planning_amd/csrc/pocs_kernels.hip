@@ -254,6 +254,9 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
       // sample's own component when it is collision free, else 0.0; fma(1, v, acc) == acc + v and
       // fma(0, v, acc) == acc exactly, so this is the masked sum without the select instructions.
       const bool valid = (h == 0) || two;
+#if defined(POCS_ABLATE_MOMENTS)
+      acc[0][0] += x + y + t; nfree[0] += hit ? 0u : 1u; ncoll[0] += (valid && k == 0) ? 1u : 0u;
+#else
       const double xx = x * x, xy = x * y, xt = x * t, yy = y * y, yt = y * t, tt = t * t;
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
@@ -271,6 +274,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
         acc[kk][7] = fma(ind, yt, acc[kk][7]);
         acc[kk][8] = fma(ind, tt, acc[kk][8]);
       }
+#endif
     }
     if (STORE) {
       const size_t o = (size_t)r * a.sample_stride + (size_t)i0;      // sample_stride is even
