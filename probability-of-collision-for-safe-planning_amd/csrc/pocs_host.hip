@@ -61,6 +61,16 @@ struct pocs_ctx {
   unsigned long long epoch = 0;          // bumped by every setter; part of the graph cache key
   int batch = 1;                         // independent GMM estimations advanced in lockstep per call
 
+  // host image (headers | chains | initial mixtures) of the NEXT batch, computed while the GPU
+  // works on the current one
+  struct {
+    bool valid = false;
+    uint64_t seed = 0, run_index = 0;
+    int R = 0;
+    unsigned long long epoch = 0;
+    std::vector<double> image, chain0, mu0, cov0;
+  } ahead;
+
   // ---- device state ----
   DevBuf d_env, d_sensor, d_hdr, d_chain, d_state, d_param, d_moments, d_partial;
   DevBuf d_sx, d_sy, d_st, d_flags, d_px, d_py, d_pt, d_hits, d_total, d_ticket, d_tables;
@@ -375,25 +385,56 @@ int gmm_prepare(pocs_ctx* c) {
 
 // host staging -> device: run header, chain, initial mixture (initGMM, MCSimulator.h:350-352,
 // GM_Model.h:57-77: K copies of (mu0, Sigma0), weights 1/K)
-int gmm_upload_run(pocs_ctx* c) {
+// Host image of one batch starting at run `base` (relative to c->run_index): per run the header
+// (seed), the chain record and the initial mixture (initGMM, MCSimulator.h:350-352,
+// GM_Model.h:57-77: K copies of (mu0, Sigma0), weights 1/K), laid out as the pinned staging area.
+// Leaves run 0's chain in c->h_chain / h_mu / h_cov.
+void build_run_image(pocs_ctx* c, uint64_t base, double* img) {
   const PinLayout pl = pin_layout(c);
-  double* pin = (double*)c->h_pin;
   const int W = c->W, R = c->batch;
   const size_t steps = (size_t)(W > 1 ? W - 1 : 1);
-  std::vector<double> chain0, mu0, cov0;
   for (int r = R - 1; r >= 0; --r) {          // run 0 last: c->h_chain / h_mu / h_cov keep ITS chain
-    const uint64_t seed = effective_seed(c, (uint64_t)r);
+    const uint64_t seed = effective_seed(c, base + (uint64_t)r);
     compute_chain(c, seed);
     pocs_run_header hdr; hdr.seed = seed; hdr.pad = 0;
-    memcpy(pin + 2 * (size_t)r, &hdr, sizeof hdr);
-    memcpy(pin + pl.chain + (size_t)r * steps * POCS_CHAIN_STRIDE, c->h_chain.data(), c->h_chain.size() * sizeof(double));
+    memcpy(img + 2 * (size_t)r, &hdr, sizeof hdr);
+    memcpy(img + pl.chain + (size_t)r * steps * POCS_CHAIN_STRIDE, c->h_chain.data(), c->h_chain.size() * sizeof(double));
     for (int k = 0; k < c->K; ++k) {
-      double* s = pin + pl.state0 + ((size_t)r * c->K + k) * POCS_STATE_STRIDE;
+      double* s = img + pl.state0 + ((size_t)r * c->K + k) * POCS_STATE_STRIDE;
       s[0] = c->traj[0]; s[1] = c->traj[W]; s[2] = c->traj[2 * W];
       memcpy(s + 3, c->cov0, 9 * sizeof(double));
       s[12] = 1.0 / c->K; s[13] = 1.0; s[14] = 0.0; s[15] = 0.0;
     }
   }
+}
+
+// While the GPU works on the current batch: the host chains of the next one.
+void prefetch_next_batch(pocs_ctx* c) {
+  const PinLayout pl = pin_layout(c);
+  auto& a = c->ahead;
+  std::vector<double> keep_chain = c->h_chain, keep_mu = c->h_mu, keep_cov = c->h_cov;
+  a.image.resize(pl.moments);
+  build_run_image(c, 0, a.image.data());       // c->run_index already points at the next batch
+  a.chain0.swap(c->h_chain); a.mu0.swap(c->h_mu); a.cov0.swap(c->h_cov);
+  c->h_chain.swap(keep_chain); c->h_mu.swap(keep_mu); c->h_cov.swap(keep_cov);
+  a.seed = c->seed; a.run_index = c->run_index; a.R = c->batch; a.epoch = c->epoch;
+  a.valid = true;
+}
+
+int gmm_upload_run(pocs_ctx* c) {
+  const PinLayout pl = pin_layout(c);
+  double* pin = (double*)c->h_pin;
+  const int W = c->W, R = c->batch;
+  const size_t steps = (size_t)(W > 1 ? W - 1 : 1);
+  auto& a = c->ahead;
+  if (a.valid && a.seed == c->seed && a.run_index == c->run_index && a.R == R && a.epoch == c->epoch &&
+      a.image.size() == pl.moments) {
+    memcpy(pin, a.image.data(), pl.moments * sizeof(double));
+    c->h_chain = a.chain0; c->h_mu = a.mu0; c->h_cov = a.cov0;
+  } else {
+    build_run_image(c, 0, pin);
+  }
+  a.valid = false;
   c->run_index += (uint64_t)R;
   HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, pin, (size_t)R * sizeof(pocs_run_header), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_chain.p, pin + pl.chain, (size_t)R * steps * POCS_CHAIN_STRIDE * sizeof(double),
@@ -522,6 +563,7 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
   } else {
     if (int r = enqueue_gmm_all(c, first, count, prof)) return r;
   }
+  prefetch_next_batch(c);          // host chains of the next batch, while the GPU works on this one
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (int r = prof_collect(c, (size_t)c->W)) return r;
   gmm_combine(c, (double*)c->h_pin + pin_layout(c).moments, probability);
@@ -978,6 +1020,7 @@ int pocs_gmm_end(pocs_ctx* c, double* probability) {
   const PinLayout pl = pin_layout(c);
   HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.moments, moments_dev(c),
                            (size_t)c->W * c->batch * c->K * POCS_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  prefetch_next_batch(c);          // host chains of the next batch, while the queued work drains
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (int r = prof_collect(c, (size_t)c->W)) return r;
   gmm_combine(c, (double*)c->h_pin + pl.moments, probability);
