@@ -96,8 +96,8 @@ int pocs_set_stream(pocs_ctx* ctx, void* hip_stream);                 /* launch 
 int pocs_gmm_begin(pocs_ctx* ctx);
 int pocs_gmm_step_local(pocs_ctx* ctx, int waypoint);
 void* pocs_gmm_moments_ptr(pocs_ctx* ctx, int waypoint);              /* device pointer, f64[moments_len] */
-int pocs_gmm_moments_len(const pocs_ctx* ctx);
-int pocs_gmm_bind_moments(pocs_ctx* ctx, void* device_ptr, long long len_doubles);  /* optional: keep the [W][moments_len] moments in a caller-owned device buffer (e.g. a torch tensor handed to all_reduce); NULL unbinds */
+int pocs_gmm_moments_len(const pocs_ctx* ctx);                       /* batch x 11 x K: one exchange covers every run of the batch */
+int pocs_gmm_bind_moments(pocs_ctx* ctx, void* device_ptr, long long len_doubles);  /* optional: keep the [W][batch][11K] moments in a caller-owned device buffer (e.g. a torch tensor handed to all_reduce); NULL unbinds */
 int pocs_gmm_end(pocs_ctx* ctx, double* probability);
 /* MC: the shard's count of particles that collided at least once (device-synchronous). */
 int pocs_mc_run_local(pocs_ctx* ctx, unsigned long long* collided);

@@ -5,7 +5,7 @@
 // the reference's association, (A*B)*C, and a left-to-right inner sum; no operation is
 // contracted (the TU is built with -ffp-contract=off and these use no fma on purpose).
 // Used by: the host chain (pocs_host.hip) and the per-component device update inside
-// k_gmm_finalize (pocs_kernels.hip).
+// mixture advance of k_gmm_step / k_gmm_advance (pocs_kernels.hip).
 #pragma once
 #include "pocs_math.h"
 
