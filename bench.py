@@ -98,7 +98,7 @@ def main():
 
     # K steps are issued as `ncalls` calls of nearly equal batch: `n_hi` calls of b_hi = b_lo + 1
     # runs and the rest of b_lo runs.
-    maxb = max(1, args.batch) if path == "gmm" else 1
+    maxb = max(1, args.batch)
     ncalls = (args.steps + maxb - 1) // maxb
     b_lo, n_hi = divmod(args.steps, ncalls)
     b_hi = b_lo + 1 if n_hi else b_lo

@@ -80,7 +80,8 @@ int pocs_set_option(pocs_ctx* ctx, int option, long long value);
  * sequence advances R independent estimations in lockstep (one launch per waypoint for all of
  * them); run i of the batch draws exactly what the i-th of R consecutive single runs would have
  * drawn.  pocs_run_gmm_estimation returns run 0's probability, pocs_get_batch_probabilities all
- * R.  The per-waypoint exchange of the step API then covers R x 11K doubles.  MC is not batched. */
+ * R.  The per-waypoint exchange of the step API then covers R x 11K doubles.  runSimulation is
+ * batched the same way (pocs_mc_get_batch_counts: the shard's collided particles per run). */
 int pocs_set_batch(pocs_ctx* ctx, int runs);
 int pocs_get_batch_probabilities(pocs_ctx* ctx, double* out, int cap);
 
@@ -100,7 +101,8 @@ int pocs_gmm_moments_len(const pocs_ctx* ctx);                       /* batch x 
 int pocs_gmm_bind_moments(pocs_ctx* ctx, void* device_ptr, long long len_doubles);  /* optional: keep the [W][batch][11K] moments in a caller-owned device buffer (e.g. a torch tensor handed to all_reduce); NULL unbinds */
 int pocs_gmm_end(pocs_ctx* ctx, double* probability);
 /* MC: the shard's count of particles that collided at least once (device-synchronous). */
-int pocs_mc_run_local(pocs_ctx* ctx, unsigned long long* collided);
+int pocs_mc_run_local(pocs_ctx* ctx, unsigned long long* collided);            /* run 0 of the batch */
+int pocs_mc_get_batch_counts(pocs_ctx* ctx, unsigned long long* out, int cap);   /* every run of the last MC batch */
 
 /* ---- results of the last run, for audits and parity tests ------------------------------- */
 int pocs_get_path_length(const pocs_ctx* ctx);

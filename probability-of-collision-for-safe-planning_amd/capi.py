@@ -54,6 +54,7 @@ SIGNATURES = {
     "pocs_gmm_bind_moments": (C.c_int, [_vp, _vp, C.c_longlong]),
     "pocs_gmm_end": (C.c_int, [_vp, _dp]),
     "pocs_mc_run_local": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
+    "pocs_mc_get_batch_counts": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.c_int]),
     "pocs_get_path_length": (C.c_int, [_vp]),
     "pocs_get_waypoint_probabilities": (C.c_int, [_vp, _dp, C.c_int]),
     "pocs_get_moments": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
@@ -241,6 +242,12 @@ class Context:
         n = C.c_ulonglong()
         self._chk(self.lib.pocs_mc_run_local(self.h, C.byref(n)))
         return n.value
+
+    def mc_batch_counts(self):
+        n = getattr(self, "_batch", 1)
+        out = (C.c_ulonglong * n)()
+        got = self._chk(self.lib.pocs_mc_get_batch_counts(self.h, out, n))
+        return [int(v) for v in out[:got]]
 
     def gmm_begin(self):
         self._chk(self.lib.pocs_gmm_begin(self.h))

@@ -92,6 +92,7 @@ struct pocs_ctx {
   std::vector<double> h_mu, h_cov;       // (W-1) x 3, (W-1) x 9 : main EKF after each step
   std::vector<double> probs;             // W (run 0 of the last batch)
   std::vector<double> batch_probs;       // final probability of every run of the last batch
+  std::vector<unsigned long long> mc_counts;   // collided particles of every run of the last MC batch (this shard)
   std::vector<double> last_moments;      // W x K x 11
   long long last_gmm_count = 0, last_mc_count = 0;
   int last_gmm_wp = -1;
@@ -166,7 +167,13 @@ int grid_for(long long count, int runs = 1) {
   if (per < 8) per = 8;
   return per < one ? per : one;
 }
-int grid_for_mc(long long count) { return grid_blocks(count, POCS_BLOCK, 3); }       // MC kernels
+int grid_for_mc(long long count, int runs = 1) {                                      // MC kernels, per run
+  const int one = grid_blocks(count, POCS_BLOCK, 3);
+  if (runs <= 1) return one;
+  int per = 768 / runs;
+  if (per < 1) per = 1;
+  return per < one ? per : one;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Host chain: everything in EKF_GaussProp's loop body that does not touch particles/samples
@@ -296,7 +303,7 @@ PinLayout pin_layout(const pocs_ctx* c) {
   p.state0 = p.chain + R * (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE;
   p.moments = p.state0 + R * K * POCS_STATE_STRIDE;
   p.total = p.moments + W * R * K * POCS_NMOM;
-  p.end = p.total + 2;
+  p.end = p.total + R + 2;                 // one u64 per run: MC totals
   return p;
 }
 
@@ -421,7 +428,9 @@ void prefetch_next_batch(pocs_ctx* c) {
   a.valid = true;
 }
 
-int gmm_upload_run(pocs_ctx* c) {
+// Host image of this call's batch into the pinned staging area (from the look-ahead cache when it
+// matches), run counter advanced; then the uploads every path needs: headers and chains.
+int stage_and_upload_runs(pocs_ctx* c) {
   const PinLayout pl = pin_layout(c);
   double* pin = (double*)c->h_pin;
   const int W = c->W, R = c->batch;
@@ -439,6 +448,14 @@ int gmm_upload_run(pocs_ctx* c) {
   HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, pin, (size_t)R * sizeof(pocs_run_header), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_chain.p, pin + pl.chain, (size_t)R * steps * POCS_CHAIN_STRIDE * sizeof(double),
                            hipMemcpyHostToDevice, c->stream));
+  return POCS_OK;
+}
+
+int gmm_upload_run(pocs_ctx* c) {
+  if (int r = stage_and_upload_runs(c)) return r;
+  const PinLayout pl = pin_layout(c);
+  double* pin = (double*)c->h_pin;
+  const int W = c->W, R = c->batch;
   // the initial mixture of run r goes to state[r][0]: R rows of K*16 doubles, pitch W*K*16
   const size_t row = (size_t)c->K * POCS_STATE_STRIDE * sizeof(double);
   HIPCHK(c, hipMemcpy2DAsync(c->d_state.p, (size_t)W * row, pin + pl.state0, row, row, (size_t)R,
@@ -584,18 +601,21 @@ int mc_shard(pocs_ctx* c, long long* first, long long* count) {
 }
 
 int enqueue_mc_all(pocs_ctx* c, long long first, long long count, bool prof) {
-  const int W = c->W, nblk = grid_for_mc(count);
+  const int W = c->W, R = c->batch, nblk = grid_for_mc(count, R);
   pocs_mc_launch a;
+  memset(&a, 0, sizeof a);
   a.hdr = (const pocs_run_header*)c->d_hdr.p;
   a.env = (const pocs_env_dev*)c->d_env.p;
   a.tables = (const pocs_tables*)c->d_tables.p;
   a.chain = (const double*)c->d_chain.p;
   a.x = (double*)c->d_px.p; a.y = (double*)c->d_py.p; a.th = (double*)c->d_pt.p;
   a.hits = (uint32_t*)c->d_hits.p;
-  a.first = first; a.count = count;
+  a.total = (unsigned long long*)c->d_total.p;
+  a.first = first; a.count = count; a.stride = sample_stride_of(count);
+  a.W = W; a.nruns = R;
   a.mu0[0] = c->traj[0]; a.mu0[1] = c->traj[W]; a.mu0[2] = c->traj[2 * W];
   if (!pocs_chol3_lower(c->cov0, a.L0)) return fail(c, POCS_E_ARG, "initial covariance is not positive definite");
-  HIPCHK(c, hipMemsetAsync(c->d_total.p, 0, 16, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_total.p, 0, (size_t)R * sizeof(unsigned long long), c->stream));
   if (c->opt_fused) {
     a.step = W - 1;
     if (prof) HIPCHK(c, hipEventRecord(c->events[0], c->stream));
@@ -611,41 +631,30 @@ int enqueue_mc_all(pocs_ctx* c, long long first, long long count, bool prof) {
       if (prof) HIPCHK(c, hipEventRecord(c->events[2 * s + 1], c->stream));
     }
   }
-  HIPCHK(c, pocs_launch_mc_count(nblk, (const uint32_t*)c->d_hits.p, count,
-                                 (unsigned long long*)c->d_total.p, c->stream));
+  HIPCHK(c, pocs_launch_mc_count(nblk, a, c->stream));
   const PinLayout pl = pin_layout(c);
-  HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.total, c->d_total.p, sizeof(unsigned long long),
+  HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.total, c->d_total.p, (size_t)R * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, c->stream));
   return POCS_OK;
 }
 
-int run_mc_local(pocs_ctx* c, unsigned long long* collided) {
-  if (!collided) return fail(c, POCS_E_ARG, "null output");
+// One batch of MC roll-outs (runSimulation x batch) over this context's shard; fills c->mc_counts.
+int run_mc_local(pocs_ctx* c) {
   if (int r = check_common(c)) return r;
   if (c->num_particles < 1) return fail(c, POCS_E_STATE, "setNumParticles missing");
   long long first, count;
   if (int r = mc_shard(c, &first, &count)) return r;
   if (int r = upload_static(c)) return r;
-  const size_t W = (size_t)c->W, n = (size_t)(count > 0 ? count : 1);
-  if (int r = ensure(c, c->d_hdr, sizeof(pocs_run_header))) return r;
-  if (int r = ensure(c, c->d_chain, (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE * sizeof(double))) return r;
+  const size_t W = (size_t)c->W, R = (size_t)c->batch, n = R * (size_t)sample_stride_of(count);
+  if (int r = ensure(c, c->d_hdr, R * sizeof(pocs_run_header))) return r;
+  if (int r = ensure(c, c->d_chain, R * (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE * sizeof(double))) return r;
   if (int r = ensure(c, c->d_px, n * sizeof(double))) return r;
   if (int r = ensure(c, c->d_py, n * sizeof(double))) return r;
   if (int r = ensure(c, c->d_pt, n * sizeof(double))) return r;
   if (int r = ensure(c, c->d_hits, n * sizeof(uint32_t))) return r;
-  if (int r = ensure(c, c->d_total, 16)) return r;
+  if (int r = ensure(c, c->d_total, R * sizeof(unsigned long long) + 16)) return r;
   if (int r = ensure_pin(c)) return r;
-  const uint64_t seed = effective_seed(c);
-  c->run_index++;
-  compute_chain(c, seed);
-  const PinLayout pl = pin_layout(c);       // MC always evaluates one run (slot 0 of the staging area)
-  double* pin = (double*)c->h_pin;
-  pocs_run_header hdr; hdr.seed = seed; hdr.pad = 0;
-  memcpy(pin, &hdr, sizeof hdr);
-  memcpy(pin + pl.chain, c->h_chain.data(), c->h_chain.size() * sizeof(double));
-  HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, pin, sizeof hdr, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_chain.p, pin + pl.chain, c->h_chain.size() * sizeof(double),
-                           hipMemcpyHostToDevice, c->stream));
+  if (int r = stage_and_upload_runs(c)) return r;
   const bool prof = c->opt_profile != 0;
   const size_t nprof = c->opt_fused ? 1 : (W > 1 ? W - 1 : 0);
   if (int r = prof_begin(c, nprof > 0 ? nprof : 1)) return r;
@@ -668,11 +677,12 @@ int run_mc_local(pocs_ctx* c, unsigned long long* collided) {
   } else {
     if (int r = enqueue_mc_all(c, first, count, prof)) return r;
   }
+  prefetch_next_batch(c);          // host chains of the next batch, while the GPU works on this one
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (int r = prof_collect(c, nprof)) return r;
-  unsigned long long tot;
-  memcpy(&tot, pin + pl.total, sizeof tot);
-  *collided = tot;
+  const PinLayout pl = pin_layout(c);
+  c->mc_counts.resize(R);
+  memcpy(c->mc_counts.data(), (double*)c->h_pin + pl.total, R * sizeof(unsigned long long));
   c->last_mc_count = count;
   return POCS_OK;
 }
@@ -966,17 +976,29 @@ int pocs_run_simulation(pocs_ctx* c, double* probability) {
   if (!c) return POCS_E_ARG;
   if (!probability) return fail(c, POCS_E_ARG, "null output");
   HIPCHK(c, hipSetDevice(c->device));
-  unsigned long long tot = 0;
-  if (int r = run_mc_local(c, &tot)) return r;
+  if (int r = run_mc_local(c)) return r;
   // getCollisionProportion, MCSimulator.h:324-330 (of the particles this context evaluated)
-  *probability = (double)tot / (double)(c->last_mc_count > 0 ? c->last_mc_count : 1);
+  const double den = (double)(c->last_mc_count > 0 ? c->last_mc_count : 1);
+  c->batch_probs.assign(c->mc_counts.size(), 0.0);
+  for (size_t r = 0; r < c->mc_counts.size(); ++r) c->batch_probs[r] = (double)c->mc_counts[r] / den;
+  *probability = c->batch_probs[0];
   return POCS_OK;
 }
 
 int pocs_mc_run_local(pocs_ctx* c, unsigned long long* collided) {
   if (!c) return POCS_E_ARG;
+  if (!collided) return fail(c, POCS_E_ARG, "null output");
   HIPCHK(c, hipSetDevice(c->device));
-  return run_mc_local(c, collided);
+  if (int r = run_mc_local(c)) return r;
+  *collided = c->mc_counts[0];
+  return POCS_OK;
+}
+
+int pocs_mc_get_batch_counts(pocs_ctx* c, unsigned long long* out, int cap) {
+  if (!c || !out) return POCS_E_ARG;
+  if ((int)c->mc_counts.size() > cap) return fail(c, POCS_E_BUFFER, "need %zu counters", c->mc_counts.size());
+  memcpy(out, c->mc_counts.data(), c->mc_counts.size() * sizeof(unsigned long long));
+  return (int)c->mc_counts.size();
 }
 
 int pocs_gmm_begin(pocs_ctx* c) {

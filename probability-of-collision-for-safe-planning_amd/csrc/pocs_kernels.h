@@ -57,17 +57,21 @@ struct pocs_gmm_launch {
   int advance_in_tail;           // 1: the last block also builds state/param[waypoint+1] (single GPU)
 };
 
-struct pocs_mc_launch {
-  const pocs_run_header* hdr;
+struct pocs_mc_launch {               // blockIdx.y = run of the batch, like pocs_gmm_launch
+  const pocs_run_header* hdr;          // [nruns]
   const pocs_env_dev* env;
   const pocs_tables* tables;
-  const double* chain;                 // noisy control of step s at chain[s*STRIDE+6..8]
-  double* x; double* y; double* th;    // SoA particle state of this shard
-  uint32_t* hits;                      // particlecollisions
+  const double* chain;                 // [nruns][W-1][STRIDE]: noisy control of step s at [..][s][6..8]
+  double* x; double* y; double* th;    // SoA particle state [nruns][stride] of this shard
+  uint32_t* hits;                      // particlecollisions [nruns][stride]
+  unsigned long long* total;           // [nruns] particles with hits > 0
   long long first, count;
+  long long stride;                    // >= count
+  int W;
   double mu0[3];
   double L0[6];
   int step;                            // k_mc_step: control index; k_mc_fused: number of steps
+  int nruns;
 };
 
 hipError_t pocs_launch_gmm_step(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);
@@ -75,5 +79,4 @@ hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t 
 hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s);
 hipError_t pocs_launch_mc_step(int nblk, const pocs_mc_launch& a, hipStream_t s);
 hipError_t pocs_launch_mc_fused(int nblk, const pocs_mc_launch& a, hipStream_t s);
-hipError_t pocs_launch_mc_count(int nblk, const uint32_t* hits, long long count,
-                                unsigned long long* total, hipStream_t s);
+hipError_t pocs_launch_mc_count(int nblk, const pocs_mc_launch& a, hipStream_t s);

@@ -356,6 +356,24 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   }
 }
 
+// MC kernels: blockIdx.y = run of the batch (its own seed, its own noisy controls, its own slice
+// of the particle arrays).
+struct mc_run_view {
+  uint64_t seed;
+  const double* chain;
+  double* x; double* y; double* th;
+  uint32_t* hits;
+};
+__device__ __forceinline__ mc_run_view mc_view(const pocs_mc_launch& a) {
+  const int r = blockIdx.y;
+  const size_t o = (size_t)r * (size_t)a.stride;
+  mc_run_view v;
+  v.seed = a.hdr[r].seed;
+  v.chain = a.chain + (size_t)r * (a.W > 1 ? a.W - 1 : 1) * POCS_CHAIN_STRIDE;
+  v.x = a.x + o; v.y = a.y + o; v.th = a.th + o; v.hits = a.hits + o;
+  return v;
+}
+
 __global__ __launch_bounds__(POCS_BLOCK) void k_mc_init(pocs_mc_launch a) {
   __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
   __shared__ pocs_footprint s_fp;
@@ -364,19 +382,19 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_init(pocs_mc_launch a) {
   stage_env(a.env, s_obs, &s_fp, &s_M);
   stage_tables(a.tables, &s_tab);
   __syncthreads();
-  const uint64_t seed = a.hdr->seed;
+  const mc_run_view v = mc_view(a);
   const pocs_footprint fp = s_fp;
   const int M = s_M;
   const long long stride = (long long)gridDim.x * POCS_BLOCK;
   for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < a.count; i += stride) {
     double z[3];
     uint32_t spare;
-    pocs_normal3(seed, (uint64_t)(a.first + i), 0u, POCS_STREAM_MCINIT, z, &spare);
+    pocs_normal3(v.seed, (uint64_t)(a.first + i), 0u, POCS_STREAM_MCINIT, z, &spare);
     const double x = fma(a.L0[0], z[0], a.mu0[0]);
     const double y = fma(a.L0[2], z[1], fma(a.L0[1], z[0], a.mu0[1]));
     const double t = fma(a.L0[5], z[2], fma(a.L0[4], z[1], fma(a.L0[3], z[0], a.mu0[2])));
-    a.x[i] = x; a.y[i] = y; a.th[i] = t;
-    a.hits[i] = pocs_pose_collides(x, y, t, &fp, s_obs, M, &s_tab) ? 1u : 0u;
+    v.x[i] = x; v.y[i] = y; v.th[i] = t;
+    v.hits[i] = pocs_pose_collides(x, y, t, &fp, s_obs, M, &s_tab) ? 1u : 0u;
   }
 }
 
@@ -388,20 +406,21 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_step(pocs_mc_launch a) {
   stage_env(a.env, s_obs, &s_fp, &s_M);
   stage_tables(a.tables, &s_tab);
   __syncthreads();
+  const mc_run_view v = mc_view(a);
   const pocs_footprint fp = s_fp;
   const int M = s_M;
-  const double* u = a.chain + (size_t)a.step * POCS_CHAIN_STRIDE + 6;
+  const double* u = v.chain + (size_t)a.step * POCS_CHAIN_STRIDE + 6;
   const double u0 = u[0], u1 = u[1], u2 = u[2];
   const long long stride = (long long)gridDim.x * POCS_BLOCK;
   for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < a.count; i += stride) {
-    const double x = a.x[i], y = a.y[i], t = a.th[i];
+    const double x = v.x[i], y = v.y[i], t = v.th[i];
     double sn, cs;
     pocs_sincos(t + u0, &sn, &cs);
     const double nx = fma(u1, cs, x);
     const double ny = fma(u1, sn, y);
     const double nt = pocs_wrap_angle(t + u0 + u2);
-    a.x[i] = nx; a.y[i] = ny; a.th[i] = nt;
-    if (pocs_pose_collides(nx, ny, nt, &fp, s_obs, M, &s_tab)) a.hits[i] += 1u;
+    v.x[i] = nx; v.y[i] = ny; v.th[i] = nt;
+    if (pocs_pose_collides(nx, ny, nt, &fp, s_obs, M, &s_tab)) v.hits[i] += 1u;
   }
 }
 
@@ -413,20 +432,20 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_fused(pocs_mc_launch a) {
   stage_env(a.env, s_obs, &s_fp, &s_M);
   stage_tables(a.tables, &s_tab);
   __syncthreads();
-  const uint64_t seed = a.hdr->seed;
+  const mc_run_view v = mc_view(a);
   const pocs_footprint fp = s_fp;
   const int M = s_M;
   const long long stride = (long long)gridDim.x * POCS_BLOCK;
   for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < a.count; i += stride) {
     double z[3];
     uint32_t spare;
-    pocs_normal3(seed, (uint64_t)(a.first + i), 0u, POCS_STREAM_MCINIT, z, &spare);
+    pocs_normal3(v.seed, (uint64_t)(a.first + i), 0u, POCS_STREAM_MCINIT, z, &spare);
     double x = fma(a.L0[0], z[0], a.mu0[0]);
     double y = fma(a.L0[2], z[1], fma(a.L0[1], z[0], a.mu0[1]));
     double t = fma(a.L0[5], z[2], fma(a.L0[4], z[1], fma(a.L0[3], z[0], a.mu0[2])));
     unsigned h = pocs_pose_collides(x, y, t, &fp, s_obs, M, &s_tab) ? 1u : 0u;
     for (int s = 0; s < a.step; ++s) {
-      const double* u = a.chain + (size_t)s * POCS_CHAIN_STRIDE + 6;   // wave-uniform
+      const double* u = v.chain + (size_t)s * POCS_CHAIN_STRIDE + 6;   // wave-uniform
       const double u0 = u[0], u1 = u[1], u2 = u[2];
       double sn, cs;
       pocs_sincos(t + u0, &sn, &cs);
@@ -435,26 +454,25 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_fused(pocs_mc_launch a) {
       t = pocs_wrap_angle(t + u0 + u2);
       h += pocs_pose_collides(x, y, t, &fp, s_obs, M, &s_tab) ? 1u : 0u;
     }
-    a.x[i] = x; a.y[i] = y; a.th[i] = t;
-    a.hits[i] = h;
+    v.x[i] = x; v.y[i] = y; v.th[i] = t;
+    v.hits[i] = h;
   }
 }
 
-__global__ __launch_bounds__(POCS_BLOCK) void k_mc_count(const uint32_t* __restrict__ hits,
-                                                         long long count,
-                                                         unsigned long long* total) {
+__global__ __launch_bounds__(POCS_BLOCK) void k_mc_count(pocs_mc_launch a) {
   __shared__ unsigned s_w[POCS_BLOCK / 64];
+  const mc_run_view v = mc_view(a);
   unsigned c = 0;
   const long long stride = (long long)gridDim.x * POCS_BLOCK;
-  for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < count; i += stride)
-    c += hits[i] > 0u ? 1u : 0u;
+  for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < a.count; i += stride)
+    c += v.hits[i] > 0u ? 1u : 0u;
   c = wave_sum_u32(c);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long t = 0;
     for (int w = 0; w < POCS_BLOCK / 64; ++w) t += s_w[w];
-    if (t) atomicAdd(total, t);      // integer atomic: order independent, exact
+    if (t) atomicAdd(&a.total[blockIdx.y], t);      // integer atomic: order independent, exact
   }
 }
 
@@ -486,19 +504,18 @@ hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t 
   return hipGetLastError();
 }
 hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_mc_init, dim3(nblk), dim3(POCS_BLOCK), 0, s, a);
+  hipLaunchKernelGGL(k_mc_init, dim3(nblk, a.nruns), dim3(POCS_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 hipError_t pocs_launch_mc_step(int nblk, const pocs_mc_launch& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_mc_step, dim3(nblk), dim3(POCS_BLOCK), 0, s, a);
+  hipLaunchKernelGGL(k_mc_step, dim3(nblk, a.nruns), dim3(POCS_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 hipError_t pocs_launch_mc_fused(int nblk, const pocs_mc_launch& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_mc_fused, dim3(nblk), dim3(POCS_BLOCK), 0, s, a);
+  hipLaunchKernelGGL(k_mc_fused, dim3(nblk, a.nruns), dim3(POCS_BLOCK), 0, s, a);
   return hipGetLastError();
 }
-hipError_t pocs_launch_mc_count(int nblk, const uint32_t* hits, long long count,
-                                unsigned long long* total, hipStream_t s) {
-  hipLaunchKernelGGL(k_mc_count, dim3(nblk), dim3(POCS_BLOCK), 0, s, hits, count, total);
+hipError_t pocs_launch_mc_count(int nblk, const pocs_mc_launch& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_mc_count, dim3(nblk, a.nruns), dim3(POCS_BLOCK), 0, s, a);
   return hipGetLastError();
 }

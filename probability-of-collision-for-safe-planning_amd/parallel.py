@@ -67,11 +67,14 @@ def run_gmm_pipelined(engines, dist):
 
 
 def run_mc_sharded(engine, n_total, dist=None):
-    """engine: mc_local() -> tensor [1] int64 with the shard's collided count."""
+    """engine: mc_local() -> int64 tensor with the shard's collided count of every run of the
+    batch.  Returns run 0's probability (all of them: engine.last_mc_probabilities)."""
     cnt = engine.mc_local()
     if dist is not None:
         dist.all_reduce(cnt)
-    return int(cnt.item()) / float(n_total)
+    probs = [int(v) / float(n_total) for v in cnt.tolist()]
+    engine.last_mc_probabilities = probs
+    return probs[0]
 
 
 class GpuEngine:
@@ -120,4 +123,5 @@ class GpuEngine:
         return self.ctx.batch_probabilities()
 
     def mc_local(self):
-        return self.torch.tensor([self.ctx.mc_run_local()], dtype=self.torch.int64, device="cuda")
+        self.ctx.mc_run_local()
+        return self.torch.tensor(self.ctx.mc_batch_counts(), dtype=self.torch.int64, device="cuda")

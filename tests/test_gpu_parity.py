@@ -185,6 +185,28 @@ def test_batch_equals_consecutive_single_runs(ctx, plan, env):
     assert ctx.run_gmm_estimation() == seq[0]
 
 
+def test_mc_batch_equals_consecutive_single_runs(ctx, pocs, plan, env):
+    N = 3001
+    ctx.configure(plan, env, K=3, N=N, seed=23)
+    seq = [ctx.run_simulation() for _ in range(4)]
+    ctx.set_seed(23)
+    ctx.run_simulation()
+    x0, h0 = ctx.particles(N)
+    for fused in (0, 1):
+        ctx.set_option(pocs.OPT_MC_FUSED, fused)
+        ctx.set_seed(23)
+        ctx.set_batch(4)
+        try:
+            assert ctx.run_simulation() == seq[0]
+            assert list(ctx.batch_probabilities()) == seq
+            assert ctx.mc_batch_counts() == [round(p * N) for p in seq]
+            x, h = ctx.particles(N)                               # run 0 of the batch
+            assert np.array_equal(x, x0) and np.array_equal(h, h0)
+        finally:
+            ctx.set_batch(1)
+    ctx.set_option(pocs.OPT_MC_FUSED, 0)
+
+
 def test_pipelined_engines_match_single_runs(pocs, plan, env):
     """parallel.GpuEngine / run_gmm_pipelined (what bench.py runs per rank over RCCL), here without
     a process group: two engines on two torch streams, batches of 2, must reproduce the four
