@@ -95,6 +95,7 @@ class GpuEngine:
         ctx.set_stream((stream or torch.cuda.current_stream()).cuda_stream)
         self.buf = torch.zeros(W * batch * K * 11, dtype=torch.float64, device="cuda")   # [W][batch][K*11]
         ctx.gmm_bind_moments(self.buf.data_ptr(), self.buf.numel())
+        torch.cuda.synchronize()               # the zero fill ran on torch's default stream
 
     def stream_ctx(self):
         import contextlib
