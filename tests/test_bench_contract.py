@@ -1,0 +1,41 @@
+"""bench.py prints ONE JSON line with the contract's fields (GPU)."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*extra):
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "5", "--warmup", "2", "--samples", "20000",
+                          "--cpu-evals", "2e5", *extra], capture_output=True, text=True, check=True, cwd=str(ROOT))
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_default_line_has_every_field():
+    d = run_bench()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert sum(d["config"]["calls"]) == 5
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert r["algorithmic_bytes_per_launch"] == 26 * r["evals_per_launch"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] > 0 and abs(d["value"] - 20000 * 56 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-9
+
+
+def test_mc_workload_line():
+    d = run_bench("--workload", "mc", "--no-cpu-baseline")
+    assert "MC" in d["metric"] and d["roofline"]["bytes_per_eval"] == 56 and "cpu_baseline" not in d
