@@ -1,0 +1,69 @@
+"""The N > 1 GPU path end to end on ONE card: two processes share the GPU (gloo moves the moments
+between them), each evaluates its shard through libpocs.so with parallel.GpuEngine /
+run_gmm_pipelined / run_mc_sharded -- exactly what bench.py does per rank over RCCL.  The sharded
+result must equal the one-process result for the same total sample count."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, n_local, K, seed, batch, out):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from importlib import import_module
+    import pocs_amd
+    par = import_module("probability-of-collision-for-safe-planning_amd.parallel")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan, env = pocs_amd.load_plan(), pocs_amd.load_env()
+    N = n_local * world
+    ctxs, engs = [], []
+    for i in range(2):                                    # two engines in flight, as in bench.py
+        c = pocs_amd.Context(0)
+        c.configure(plan, env, K=K, N=N, seed=seed + i)
+        ctxs.append(c)
+        engs.append(par.GpuEngine(c, 56, K, N, rank=rank, world=world, per_rank=n_local, batch=batch,
+                                  stream=torch.cuda.Stream()))
+    par.run_gmm_pipelined(engs, dist)
+    torch.cuda.synchronize()
+    probs = [list(e.probabilities()) for e in engs]
+    ctxs[0].set_seed(seed)
+    p_mc = par.run_mc_sharded(engs[0], N, dist)
+    mc_all = engs[0].last_mc_probabilities
+    if rank == 0:
+        np.save(out, np.array(probs[0] + probs[1] + mc_all + [p_mc]))
+    for c in ctxs:
+        c.close()
+    dist.destroy_process_group()
+
+
+def test_two_processes_one_gpu_equal_one_process(tmp_path, pocs, plan, env):
+    import torch.multiprocessing as mp
+    n_local, K, seed, batch = 5000, 3, 77, 2
+    out = tmp_path / "res.npy"
+    port = 29700 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(2, port, n_local, K, seed, batch, str(out)), nprocs=2, join=True)
+    got = np.load(out)
+    N = 2 * n_local
+    want, want_mc = [], []
+    with pocs.Context(0) as c:
+        for s in (seed, seed + 1):
+            c.configure(plan, env, K=K, N=N, seed=s)
+            c.set_batch(batch)
+            c.run_gmm_estimation()
+            want += list(c.batch_probabilities())
+        c.configure(plan, env, K=K, N=N, seed=seed)
+        c.set_batch(batch)
+        c.run_simulation()
+        want_mc = list(c.batch_probabilities())
+    assert np.allclose(got[:4], want, rtol=0, atol=1e-12)         # two ranks' moment sums added in another order
+    assert list(got[4:6]) == want_mc and got[6] == want_mc[0]      # integer counts: exact
