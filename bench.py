@@ -78,6 +78,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "POCS_FORCE_DEVICE" in os.environ:            # rehearsal: several ranks on one card (gloo)
+        local = int(os.environ["POCS_FORCE_DEVICE"])
+    backend = os.environ.get("POCS_DIST_BACKEND", "nccl")
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
@@ -85,7 +88,10 @@ def main():
     sharded = world > 1 or os.environ.get("POCS_FORCE_SHARDED") == "1"   # rehearse the N>1 path on one GPU
     if sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     W, n_local, K, path = WORKLOADS[args.workload]
     if args.samples:
