@@ -59,10 +59,10 @@ def cpu_baseline(plan, env, K, W, path, budget_evals):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=16,
                     help="independent runs (steps) advanced in lockstep per call (pocs_set_batch)")
     ap.add_argument("--samples", type=int, default=0, help="override samples per GPU (experiments only)")
     ap.add_argument("--mc-fused", action="store_true",
