@@ -251,9 +251,9 @@ void orc_sincos_tab(double x, double* s, double* c) {
   tables();
   double fn = floor(x * 1.01859163578813017e+01);
   int n = (int)fn;
-  double d = x - fn * 9.81747704208828509e-02;
-  d = d - fn * 3.79818781643997874e-12;
-  d = d - fn * 1.26391640549746914e-22;
+  double d = fma(-fn, 9.81747704208828509e-02, x);
+  d = fma(-fn, 3.79818781643997874e-12, d);
+  d = fma(-fn, 1.26391640549746914e-22, d);
   double sd, cd;
   sincos_small(d - 4.90873852123405193510e-02, &sd, &cd);
   int sec = n & 63;

@@ -29,27 +29,39 @@ POCS_HD void pocs_prepare_obstacle(const double box5[5], const pocs_footprint* f
   rec[7] = (box5[2] * fabs(sn) + box5[3] * fabs(cs)) + rr;
 }
 
-// Footprint at pose (x, y, theta) with (sn, cs) = sincos(theta) against one obstacle record.
-POCS_HD bool pocs_box_hit(double px, double py, double sn, double cs, double rx, double ry,
-                          const double* o) {
+// Narrow phase: footprint at (px, py) with heading (sn, cs) against one obstacle record that has
+// passed the broad phase.  Separating axes = the four face normals; a > b <=> a - b > 0 exactly
+// in IEEE arithmetic (gradual underflow), so the four tests fold into one compare of the largest
+// margin.  An axis-aligned obstacle (axis exactly (1, 0)) takes a shorter path that produces the
+// same values: fma(c, 1, s*0) == c, fma(dx, 1, dy*0) == dx.
+POCS_HD bool pocs_box_narrow(double px, double py, double sn, double cs, double rx, double ry,
+                             const double* o) {
   const double dx = o[0] - px;
   const double dy = o[1] - py;
-  if (fabs(dx) > o[6] || fabs(dy) > o[7]) return false;          // broad phase
   const double ax = o[2], ay = o[3], hx = o[4], hy = o[5];
-  const double acr = fabs(fma(cs, ax, sn * ay));                  // |cos| of the relative yaw
-  const double asr = fabs(fma(sn, ax, -(cs * ay)));               // |sin| of the relative yaw
+  double acr, asr, e1, e2;
+  if (ax == 1.0 && ay == 0.0) {                                   // wave-uniform
+    acr = fabs(cs); asr = fabs(sn); e1 = dx; e2 = dy;
+  } else {
+    acr = fabs(fma(cs, ax, sn * ay));                             // |cos| of the relative yaw
+    asr = fabs(fma(sn, ax, -(cs * ay)));                          // |sin| of the relative yaw
+    e1 = fma(dx, ax, dy * ay);                                    // d in the obstacle frame
+    e2 = fma(dy, ax, -(dx * ay));
+  }
   const double d1 = fma(dx, cs, dy * sn);                         // d in the footprint frame
   const double d2 = fma(dy, cs, -(dx * sn));
-  const double e1 = fma(dx, ax, dy * ay);                         // d in the obstacle frame
-  const double e2 = fma(dy, ax, -(dx * ay));
-  // separated along any of the four face normals: a > b  <=>  a - b > 0 exactly in IEEE
-  // arithmetic (gradual underflow), so the four tests fold into one compare of the largest margin
   const double m1 = fabs(d1) - (rx + fma(hx, acr, hy * asr));
   const double m2 = fabs(d2) - (ry + fma(hx, asr, hy * acr));
   const double m3 = fabs(e1) - (hx + fma(rx, acr, ry * asr));
   const double m4 = fabs(e2) - (hy + fma(rx, asr, ry * acr));
-  const bool sep = fmax(fmax(m1, m2), fmax(m3, m4)) > 0.0;
-  return !sep;
+  return !(fmax(fmax(m1, m2), fmax(m3, m4)) > 0.0);
+}
+
+// Broad phase + narrow phase against one record (host-side convenience, same result).
+POCS_HD bool pocs_box_hit(double px, double py, double sn, double cs, double rx, double ry,
+                          const double* o) {
+  if (fabs(o[0] - px) > o[6] || fabs(o[1] - py) > o[7]) return false;
+  return pocs_box_narrow(px, py, sn, cs, rx, ry, o);
 }
 
 // checkCollision for one pose: true if the footprint touches any of the M obstacles.
@@ -57,8 +69,11 @@ POCS_HD bool pocs_pose_collides(double x, double y, double th, const pocs_footpr
                                 const double* obs, int M, const pocs_tables* T) {
   double sn, cs;
   pocs_sincos_tab(th, T, &sn, &cs);
-  const double px = x + fma(cs, fp->dx, -(sn * fp->dy));
-  const double py = y + fma(sn, fp->dx, cs * fp->dy);
+  double px = x, py = y;
+  if (!(fp->dx == 0.0 && fp->dy == 0.0)) {      // a centred footprint skips x + (c*0 - s*0) == x
+    px = x + fma(cs, fp->dx, -(sn * fp->dy));
+    py = y + fma(sn, fp->dx, cs * fp->dy);
+  }
   bool hit = false;
   for (int m = 0; m < M; ++m) hit = hit | pocs_box_hit(px, py, sn, cs, fp->hx, fp->hy, obs + m * POCS_OBS_STRIDE);
   return hit;

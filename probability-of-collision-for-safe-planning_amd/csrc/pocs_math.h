@@ -232,9 +232,9 @@ POCS_HD void pocs_sincos_2pi_u32_tab(uint32_t w, const pocs_tables* T, double* s
 POCS_HD void pocs_sincos_tab(double x, const pocs_tables* T, double* sn, double* cs) {
   const double fn = floor(x * 1.01859163578813017e+01);
   const int n = (int)fn;
-  double d = x - fn * 9.81747704208828509e-02;        // pi/32, first 33 bits
-  d = d - fn * 3.79818781643997874e-12;               // next 33 bits
-  d = d - fn * 1.26391640549746914e-22;               // tail
+  double d = fma(-fn, 9.81747704208828509e-02, x);    // pi/32, first 33 bits (fn * it is exact)
+  d = fma(-fn, 3.79818781643997874e-12, d);           // next 33 bits
+  d = fma(-fn, 1.26391640549746914e-22, d);           // tail
   // sector centres sit at (s + 1/2) * pi/32: shift by half a sector
   double sd, cd;
   pocs_sincos_small(d - 4.90873852123405193510e-02, &sd, &cd);
