@@ -62,6 +62,7 @@ SIGNATURES = {
     "pocs_get_host_chain": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
     "pocs_copy_gmm_samples": (C.c_longlong, [_vp, _dp, C.POINTER(C.c_int16), C.c_longlong]),
     "pocs_copy_particles": (C.c_longlong, [_vp, _dp, C.POINTER(C.c_uint32), C.c_longlong]),
+    "pocs_measure_copy_bandwidth": (C.c_int, [_vp, C.c_longlong, _dp]),
     "pocs_get_kernel_time": (C.c_int, [_vp, _dp, C.POINTER(C.c_longlong)]),
 }
 
@@ -317,6 +318,12 @@ class Context:
         got = self._chk(self.lib.pocs_copy_particles(self.h, xyz.ctypes.data_as(_dp),
                                                      hits.ctypes.data_as(C.POINTER(C.c_uint32)), n))
         return xyz[:got], hits[:got]
+
+    def copy_bandwidth(self, nbytes=1 << 30):
+        """GB/s (read + written) of a plain streaming copy of nbytes on this GPU."""
+        g = C.c_double()
+        self._chk(self.lib.pocs_measure_copy_bandwidth(self.h, nbytes, C.byref(g)))
+        return g.value
 
     def kernel_time(self):
         ms, n = C.c_double(), C.c_longlong()

@@ -1138,6 +1138,37 @@ long long pocs_copy_particles(pocs_ctx* c, double* aos, uint32_t* hits, long lon
   return n;
 }
 
+// Measured streaming-copy bandwidth of this GPU (read + written bytes per second, GB/s): a plain
+// 16-B-per-lane copy of `bytes` (rounded down to 16), best of 5 timed with hipEvents on the context's
+// stream.  The ceiling the streaming kernels are compared with next to the datasheet's 8 TB/s.
+int pocs_measure_copy_bandwidth(pocs_ctx* c, long long bytes, double* gbps) {
+  if (!c || !gbps) return POCS_E_ARG;
+  if (bytes < 1024) return fail(c, POCS_E_ARG, "copy size too small");
+  HIPCHK(c, hipSetDevice(c->device));
+  bytes &= ~15LL;
+  void *a = nullptr, *b = nullptr;
+  HIPCHK(c, hipMalloc(&a, (size_t)bytes));
+  if (hipMalloc(&b, (size_t)bytes) != hipSuccess) { (void)hipFree(a); return fail(c, POCS_E_DEVICE, "hipMalloc failed"); }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipMemsetAsync(a, 1, (size_t)bytes, c->stream);
+  double best = 0.0;
+  int rc = POCS_OK;
+  for (int i = 0; i < 6 && rc == POCS_OK; ++i) {
+    (void)hipEventRecord(e0, c->stream);
+    if (pocs_launch_copy(a, b, bytes, c->stream) != hipSuccess) rc = fail(c, POCS_E_DEVICE, "copy launch failed");
+    (void)hipEventRecord(e1, c->stream);
+    if (hipEventSynchronize(e1) != hipSuccess) rc = fail(c, POCS_E_DEVICE, "copy failed");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (i > 0 && ms > 0.f) { const double g = 2.0 * (double)bytes / (ms * 1e-3) / 1e9; if (g > best) best = g; }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b);
+  *gbps = best;
+  return rc;
+}
+
 int pocs_get_kernel_time(pocs_ctx* c, double* total_ms, long long* launches) {
   if (!c) return POCS_E_ARG;
   if (total_ms) *total_ms = c->prof_ms;

@@ -76,6 +76,7 @@ struct pocs_mc_launch {               // blockIdx.y = run of the batch, like poc
 
 hipError_t pocs_launch_gmm_step(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);
 hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t s);
+hipError_t pocs_launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);
 hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s);
 hipError_t pocs_launch_mc_step(int nblk, const pocs_mc_launch& a, hipStream_t s);
 hipError_t pocs_launch_mc_fused(int nblk, const pocs_mc_launch& a, hipStream_t s);

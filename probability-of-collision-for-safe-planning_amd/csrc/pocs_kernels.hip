@@ -499,6 +499,17 @@ hipError_t pocs_launch_gmm_step(int K, int nblk, const pocs_gmm_launch& a, hipSt
   }
 }
 
+// Plain streaming copy (16 B per lane per access): the measured HBM ceiling the streaming kernels
+// are compared with next to the datasheet peak (bench.py "copy_GBps").
+__global__ __launch_bounds__(POCS_BLOCK) void k_copy(const double2* __restrict__ src, double2* __restrict__ dst, long long n) {
+  const long long stride = (long long)gridDim.x * POCS_BLOCK;
+  for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+hipError_t pocs_launch_copy(const void* src, void* dst, long long bytes, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy, dim3(2048), dim3(POCS_BLOCK), 0, s, (const double2*)src, (double2*)dst, bytes / 16);
+  return hipGetLastError();
+}
+
 hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t s) {
   hipLaunchKernelGGL(k_gmm_advance, dim3(a.nruns), dim3(64), 0, s, a, K);
   return hipGetLastError();
