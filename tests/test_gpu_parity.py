@@ -329,6 +329,42 @@ def test_limits_of_the_boundary(ctx, pocs, orc, plan):
     ctx.set_shard()
 
 
+def test_randomised_configurations_match_oracle(ctx, pocs, orc, plan):
+    """Twenty random worlds (rotated boxes, off-centre footprints, noise levels, landmark sets,
+    sub-plans, K, N, seeds): GMM flags/counts/probabilities and MC hit counters equal the oracle's."""
+    rng = np.random.default_rng(2024)
+    for case in range(20):
+        M = int(rng.integers(0, 12))
+        boxes = np.column_stack([rng.uniform(-3.8, 3.8, M), rng.uniform(-1.8, 1.8, M), rng.uniform(0.03, 0.6, M),
+                                 rng.uniform(0.03, 0.6, M), rng.choice([0.0, 0.0, 1.5707963267948966, 1.0, -0.6, 2.2], M)])
+        fp = [0.0, 0.0, float(rng.uniform(0.1, 0.4)), float(rng.uniform(0.1, 0.4))]
+        if case % 3 == 0:
+            fp[0], fp[1] = float(rng.uniform(-0.1, 0.1)), float(rng.uniform(-0.1, 0.1))
+        env_r = dict(footprint=fp, boxes=boxes.reshape(-1, 5))
+        L = int(rng.integers(1, 12))
+        lm = np.vstack([rng.uniform(-4, 4, L), rng.uniform(-2, 2, L)])
+        W = int(rng.integers(2, 57))
+        start = int(rng.integers(0, 57 - W))
+        pl = dict(traj=plan["traj"][start:start + W], odom=plan["odom"][start:start + W - 1])
+        K = int(rng.integers(1, 9))
+        N = int(rng.integers(50, 4000))
+        seed = int(rng.integers(0, 2 ** 62))
+        params = dict(pocs.DEFAULTS, landmarks=lm.tolist(), Q=float(rng.uniform(0.01, 0.1)),
+                      alphas=[float(a * rng.uniform(0.3, 3)) for a in pocs.DEFAULTS["alphas"]],
+                      cov0=(np.eye(3) * rng.uniform(2e-4, 4e-3)).tolist())
+        cfg = orc.config(pl, env_r, K=K, alphas=params["alphas"], Q=params["Q"], landmarks=lm, cov0=params["cov0"])
+        ctx.configure(pl, env_r, params=params, K=K, N=N, seed=seed)
+        p = ctx.run_gmm_estimation()
+        want = orc.run_gmm(cfg, seed, N, want_samples=True)
+        assert np.array_equal(ctx.waypoint_probabilities(), want["probs"]), case
+        assert abs(p - want["prob"]) < 1e-12, case
+        assert np.array_equal(ctx.gmm_samples(N)[1], want["flags"]), case
+        ctx.set_seed(seed)
+        p_mc = ctx.run_simulation()
+        n_mc, hits, _ = orc.run_mc(cfg, seed, N)
+        assert p_mc == n_mc / N and np.array_equal(ctx.particles(N)[1], hits), case
+
+
 def test_text_channel_is_a_drop_in(ctx, pocs, orc, plan, env):
     """The exact command sequence of MCSimulation.py:154-207,238-245 over the text channel."""
     def l2s(v):
