@@ -51,8 +51,8 @@ class Oracle:
         L.orc_run_gmm.restype = C.c_double
         L.orc_run_mc.restype = C.c_longlong
         L.orc_collides.restype = C.c_int
-        L.orc_log_unit53.restype = C.c_double
-        L.orc_log_unit53.argtypes = [C.c_uint64]
+        L.orc_log_unit32.restype = C.c_double
+        L.orc_log_unit32.argtypes = [C.c_uint32]
 
     # ---- primitives -------------------------------------------------------------------
     def philox(self, ctr, key):
@@ -75,8 +75,8 @@ class Oracle:
         self.lib.orc_sincos_2pi_u32(C.c_uint32(w), C.byref(s), C.byref(c))
         return s.value, c.value
 
-    def log_unit53(self, m):
-        return self.lib.orc_log_unit53(C.c_uint64(m))
+    def log_unit32(self, w):
+        return self.lib.orc_log_unit32(C.c_uint32(w))
 
     def sincos_tab(self, x):
         s, c = C.c_double(), C.c_double()

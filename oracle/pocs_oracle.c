@@ -205,9 +205,9 @@ static void tables(void) {
   tab_ready = 1;
 }
 
-double orc_log_unit53(uint64_t m) {   /* log(m 2^-53), 1 <= m <= 2^53 */
+double orc_log_unit32(uint32_t w) {   /* log((w + 1) 2^-32): a uniform on (0, 1] with 2^32 levels */
   tables();
-  double x = (double)m;
+  double x = (double)w + 1.0;
   uint64_t bits;
   memcpy(&bits, &x, 8);
   int e = (int)(bits >> 52) - 1023;
@@ -220,7 +220,7 @@ double orc_log_unit53(uint64_t m) {   /* log(m 2^-53), 1 <= m <= 2^53 */
   double p = co[5];
   for (int k = 4; k >= 0; --k) p = fma(r, p, co[k]);
   double l1p = fma(r * r, p, r);
-  double dk = (double)(e - 53);
+  double dk = (double)(e - 32);
   return fma(dk, 6.93147180369123816490e-01, tab_lg[i][1]) + fma(dk, 1.90821492927058770002e-10, l1p);
 }
 
@@ -262,35 +262,34 @@ void orc_sincos_tab(double x, double* s, double* c) {
   *c = fma(C, cd, -(S * sd));
 }
 
-void orc_normal_pair_tab(uint32_t w0, uint32_t w1, uint32_t w2, double* n0, double* n1) {
-  uint64_t a = (((uint64_t)w1 << 32) | w0) >> 11;
-  double radius = sqrt(-2.0 * orc_log_unit53(a + 1));
+/* Box-Muller pair of the mixture sampler: radius word wr, angle word wa. */
+void orc_normal_pair_w2(uint32_t wr, uint32_t wa, double* n0, double* n1) {
+  double radius = sqrt(-2.0 * orc_log_unit32(wr));
   double s, c;
-  orc_sincos_2pi_u32_tab(w2, &s, &c);
+  orc_sincos_2pi_u32_tab(wa, &s, &c);
   *n0 = radius * c;
   *n1 = radius * s;
 }
 
-/* mixture samples come in pairs (2j, 2j+1) that share three draws keyed by the pair index j:
- * slot 0 -> z0,z1 of 2j (+ spare of 2j); slot 1 -> z2 of 2j, z0 of 2j+1 (+ spare of 2j+1);
- * slot 2 -> z1,z2 of 2j+1.  This returns the normals and spare word of ONE sample. */
+/* mixture samples come in pairs (2j, 2j+1) that share two draws keyed by the pair index j:
+ *   slot 0: words (0,1) -> z0,z1 of 2j;  words (2,3) -> z2 of 2j, z0 of 2j+1
+ *   slot 1: words (0,1) -> z1,z2 of 2j+1;  word 2 = spare of 2j, word 3 = spare of 2j+1.
+ * This returns the normals and spare word of ONE sample. */
 void orc_sample_normals(uint64_t seed, uint64_t sample, uint32_t waypoint, uint32_t stream,
                         double z[3], uint32_t* spare) {
   uint64_t pair = sample >> 1;
-  uint32_t w0[4], w1[4], w2[4];
+  uint32_t w0[4], w1[4];
   double a, b;
+  draw(seed, pair, waypoint, stream, 0, w0);
   draw(seed, pair, waypoint, stream, 1, w1);
+  orc_normal_pair_w2(w0[2], w0[3], &a, &b);
   if ((sample & 1) == 0) {
-    draw(seed, pair, waypoint, stream, 0, w0);
-    orc_normal_pair_tab(w0[0], w0[1], w0[2], &z[0], &z[1]);
-    orc_normal_pair_tab(w1[0], w1[1], w1[2], &a, &b);
+    orc_normal_pair_w2(w0[0], w0[1], &z[0], &z[1]);
     z[2] = a;
-    *spare = w0[3];
+    *spare = w1[2];
   } else {
-    draw(seed, pair, waypoint, stream, 2, w2);
-    orc_normal_pair_tab(w1[0], w1[1], w1[2], &a, &b);
     z[0] = b;
-    orc_normal_pair_tab(w2[0], w2[1], w2[2], &z[1], &z[2]);
+    orc_normal_pair_w2(w1[0], w1[1], &z[1], &z[2]);
     *spare = w1[3];
   }
 }

@@ -32,6 +32,9 @@
 // per-block partial row; partials are combined in a fixed order so results are bitwise
 // reproducible run to run (no float atomics).
 #include "pocs_kernels.h"
+#if defined(POCS_TRACE_PHASES)
+#include <stdio.h>
+#endif
 
 namespace {
 
@@ -92,6 +95,20 @@ __device__ __forceinline__ double load_wt(const double* p) {
       reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// Thread-private moment sums kept in LDS (K <= POCS_LDS_ACC_MAXK): the add runs in the LDS unit
+// (ds_add_f64, IEEE round-to-nearest like v_add_f64), off the FP64 VALU pipe that bounds the
+// kernel, and a sample touches only its own component's nine sums instead of all 9 K.
+#ifndef POCS_LDS_ACC_MAXK
+#define POCS_LDS_ACC_MAXK 0        // off: measured neutral; 3 = K <= 3 (36 KB per component)
+#endif
+__device__ __forceinline__ void lds_add_f64(double* p, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)p, v);
+#else
+  *p += v;
+#endif
+}
+
 // Mixture bookkeeping of waypoint `w` (see pocs_gmm_advance_component), run by ONE wave: all 64
 // lanes first pull every input (state[w-1], moments[w-1], the chain record of step w-1, the
 // sensor) into LDS in one round trip, lanes < K then take one component each, lane 0 normalises,
@@ -141,9 +158,22 @@ __global__ __launch_bounds__(64) void k_gmm_advance(pocs_gmm_launch a, int K) {
   advance_mixture(a, K, a.waypoint, blockIdx.x, threadIdx.x, s_adv);      // one block per run
 }
 
+#if defined(POCS_TRACE_PHASES)     // timing-only build (tools/fixed_cost.py): 100 MHz timestamps per phase
+__device__ unsigned long long g_phase[64];
+#define POCS_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) ph[i] = wall_clock64(); } while (0)
+#else
+#define POCS_PHASE(i) do { } while (0)
+#endif
+
 template <int K, bool STORE>
 __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) {
+#if defined(POCS_TRACE_PHASES)
+  unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  POCS_PHASE(0);
   constexpr int NC = K * POCS_NMOM;
+  constexpr bool LDSACC = (K <= POCS_LDS_ACC_MAXK);
+  __shared__ double s_acc[LDSACC ? K * 9 * POCS_GMM_BLOCK : 1];     // [k][j][tid]
   __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
   __shared__ double s_par[K * POCS_PARAM_STRIDE];
   __shared__ double s_red[POCS_GMM_BLOCK / 16][NC];     // one row of sums per 16-lane DPP row
@@ -167,19 +197,26 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
     s_par[j] = a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j];
   const uint64_t seed = a.hdr[r].seed;
 
-  double acc[K][9];
+  double acc[LDSACC ? 1 : K][9];
   unsigned nfree[K], ncoll[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     nfree[k] = 0u; ncoll[k] = 0u;
+    if (LDSACC) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j) acc[k][j] = 0.0;
+      for (int j = 0; j < 9; ++j) s_acc[(k * 9 + j) * POCS_GMM_BLOCK + tid] = 0.0;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc[k][j] = 0.0;
+    }
   }
   __syncthreads();
+  POCS_PHASE(1);
 
   // ---- head, part 2: cull the obstacle table against the mixture's bounding box.  A Box-Muller
-  // normal is bounded: u >= 2^-53 gives |z| <= sqrt(106 ln 2) < 8.58, so every pose this launch
-  // can draw lies within mean_k +- 8.58 (|L00|, |L10|+|L11|) of some component; an obstacle whose
+  // normal is bounded: u >= 2^-32 gives |z| <= sqrt(64 ln 2) < 6.661 (pocs_normal_pair_w2; 6.67 leaves
+  // 0.1 % for the rounding of radius * cos), so every pose this launch can draw lies within
+  // mean_k +- 6.67 (|L00|, |L10|+|L11|) of some component; an obstacle whose
   // inflated box (the broad phase of pocs_box_hit) misses that region is rejected by the broad
   // phase for every sample, so dropping it here changes no flag.
   if (tid < 64) {
@@ -187,7 +224,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const double* p = &s_par[k * POCS_PARAM_STRIDE];
-      const double ex = 8.58 * fabs(p[3]), ey = 8.58 * (fabs(p[4]) + fabs(p[5]));
+      const double ex = 6.67 * fabs(p[3]), ey = 6.67 * (fabs(p[4]) + fabs(p[5]));
       xlo = fmin(xlo, p[0] - ex); xhi = fmax(xhi, p[0] + ex);
       ylo = fmin(ylo, p[1] - ey); yhi = fmax(yhi, p[1] + ey);
     }
@@ -208,9 +245,13 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   }
   __syncthreads();
   const int nkeep = s_nkeep;
+  POCS_PHASE(2);
+#if defined(POCS_TRACE_PHASES)
+  if (threadIdx.x == 0 && blockIdx.y == 0) ph[10] = __builtin_readcyclecounter();
+#endif
 
-  // ---- body: one PAIR of samples (2j, 2j+1) per thread and iteration -- the pair shares three
-  // Philox draws / Box-Muller pairs (pocs_normal3_pair) and its poses leave as 16-byte stores.
+  // ---- body: one PAIR of samples (2j, 2j+1) per thread and iteration -- the pair shares two
+  // Philox draws = three Box-Muller pairs (pocs_normal3_pair) and its poses leave as 16-byte stores.
   // a.first is even (checked by the host), so local sample 2*lp is global sample first + 2*lp.
   const long long stride = (long long)gridDim.x * POCS_GMM_BLOCK;
   const long long npairs = (a.count + 1) >> 1;
@@ -258,21 +299,42 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
       acc[0][0] += x + y + t; nfree[0] += hit ? 0u : 1u; ncoll[0] += (valid && k == 0) ? 1u : 0u;
 #else
       const double xx = x * x, xy = x * y, xt = x * t, yy = y * y, yt = y * t, tt = t * t;
+      if (LDSACC) {
 #pragma unroll
-      for (int kk = 0; kk < K; ++kk) {
-        const bool sel = valid && (k == kk);
-        nfree[kk] += (sel && !hit) ? 1u : 0u;
-        ncoll[kk] += (sel && hit) ? 1u : 0u;
-        const double ind = (sel && !hit) ? 1.0 : 0.0;
-        acc[kk][0] = fma(ind, x, acc[kk][0]);
-        acc[kk][1] = fma(ind, y, acc[kk][1]);
-        acc[kk][2] = fma(ind, t, acc[kk][2]);
-        acc[kk][3] = fma(ind, xx, acc[kk][3]);
-        acc[kk][4] = fma(ind, xy, acc[kk][4]);
-        acc[kk][5] = fma(ind, xt, acc[kk][5]);
-        acc[kk][6] = fma(ind, yy, acc[kk][6]);
-        acc[kk][7] = fma(ind, yt, acc[kk][7]);
-        acc[kk][8] = fma(ind, tt, acc[kk][8]);
+        for (int kk = 0; kk < K; ++kk) {
+          const bool sel = valid && (k == kk);
+          nfree[kk] += (sel && !hit) ? 1u : 0u;
+          ncoll[kk] += (sel && hit) ? 1u : 0u;
+        }
+        if (valid && !hit) {
+          double* q = &s_acc[k * (9 * POCS_GMM_BLOCK) + tid];
+          lds_add_f64(q + 0 * POCS_GMM_BLOCK, x);
+          lds_add_f64(q + 1 * POCS_GMM_BLOCK, y);
+          lds_add_f64(q + 2 * POCS_GMM_BLOCK, t);
+          lds_add_f64(q + 3 * POCS_GMM_BLOCK, xx);
+          lds_add_f64(q + 4 * POCS_GMM_BLOCK, xy);
+          lds_add_f64(q + 5 * POCS_GMM_BLOCK, xt);
+          lds_add_f64(q + 6 * POCS_GMM_BLOCK, yy);
+          lds_add_f64(q + 7 * POCS_GMM_BLOCK, yt);
+          lds_add_f64(q + 8 * POCS_GMM_BLOCK, tt);
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+          const bool sel = valid && (k == kk);
+          nfree[kk] += (sel && !hit) ? 1u : 0u;
+          ncoll[kk] += (sel && hit) ? 1u : 0u;
+          const double ind = (sel && !hit) ? 1.0 : 0.0;
+          acc[kk][0] = fma(ind, x, acc[kk][0]);
+          acc[kk][1] = fma(ind, y, acc[kk][1]);
+          acc[kk][2] = fma(ind, t, acc[kk][2]);
+          acc[kk][3] = fma(ind, xx, acc[kk][3]);
+          acc[kk][4] = fma(ind, xy, acc[kk][4]);
+          acc[kk][5] = fma(ind, xt, acc[kk][5]);
+          acc[kk][6] = fma(ind, yy, acc[kk][6]);
+          acc[kk][7] = fma(ind, yt, acc[kk][7]);
+          acc[kk][8] = fma(ind, tt, acc[kk][8]);
+        }
       }
 #endif
     }
@@ -290,6 +352,10 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
     }
   }
 
+  POCS_PHASE(3);
+#if defined(POCS_TRACE_PHASES)
+  if (threadIdx.x == 0 && blockIdx.y == 0) ph[11] = __builtin_readcyclecounter() - ph[10];
+#endif
   // ---- tail: DPP row sums -> one LDS row per 16 lanes -> fixed-order sum over the 32 rows
   {
     const int row = tid >> 4;
@@ -301,12 +367,13 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
       if (writer) { s_red[row][k * POCS_NMOM] = (double)nf; s_red[row][k * POCS_NMOM + 1] = (double)nc; }
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
-        const double v = row_sum(acc[k][j]);
+        const double v = row_sum(LDSACC ? s_acc[(k * 9 + j) * POCS_GMM_BLOCK + tid] : acc[LDSACC ? 0 : k][j]);
         if (writer) s_red[row][k * POCS_NMOM + 2 + j] = v;
       }
     }
   }
   __syncthreads();
+  POCS_PHASE(4);
   if (tid < NC) {
     double v = s_red[0][tid];
 #pragma unroll 8
@@ -318,11 +385,16 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   // in a fixed order: slice q of column c sums rows q, q+S, q+2S, ...; then slices in order.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  POCS_PHASE(5);
   if (tid == 0) {
     const unsigned t = __hip_atomic_fetch_add(&a.ticket[(size_t)r * a.W + w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == gridDim.x - 1u) ? 1 : 0;
   }
   __syncthreads();
+  POCS_PHASE(6);
+#if defined(POCS_TRACE_PHASES)
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x == 0 && a.waypoint == 5) for (int i = 0; i < 12; ++i) g_phase[32 + i] = ph[i];
+#endif
   if (s_last) {
     constexpr int S = POCS_GMM_BLOCK / NC;
     const int q = tid / NC, c = tid - q * NC;
@@ -342,6 +414,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
     }
     s_part[tid] = v;
     __syncthreads();
+    POCS_PHASE(7);
     if (tid < NC) {
       double tot = s_part[tid];
       for (int sl = 1; sl < S; ++sl) tot += s_part[sl * NC + tid];
@@ -351,8 +424,13 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
     // here (one wave; the other 255 CUs are already idle) instead of paying another launch
     if (a.advance_in_tail) {
       __syncthreads();
+      POCS_PHASE(8);
       if (tid < 64) advance_mixture(a, K, w + 1, r, tid, s_adv);
     }
+    POCS_PHASE(9);
+#if defined(POCS_TRACE_PHASES)
+    if (tid == 0 && blockIdx.y == 0 && a.waypoint == 5) { for (int i = 0; i < 12; ++i) g_phase[i] = ph[i]; g_phase[12] = blockIdx.x; }
+#endif
   }
 }
 
@@ -486,6 +564,21 @@ hipError_t launch_gmm_k(int nblk, const pocs_gmm_launch& a, hipStream_t s) {
 }  // namespace
 
 hipError_t pocs_launch_gmm_step(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s) {
+#if defined(POCS_TRACE_PHASES)
+  if (a.waypoint == 6) {         // waypoint 5 has run: print its phase stamps (10 ns ticks), once per call
+    unsigned long long h[64];
+    hipStreamSynchronize(s);
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) == hipSuccess) {
+      fprintf(stderr, "phases last block (bx=%llu) us:", h[12]);
+      for (int i = 1; i < 10; ++i) fprintf(stderr, " %d:%.2f", i, 0.01 * (double)(long long)(h[i] - h[0]));
+      fprintf(stderr, "\nphases block 0 us:");
+      for (int i = 1; i < 7; ++i) fprintf(stderr, " %d:%.2f", i, 0.01 * (double)(long long)(h[32 + i] - h[32]));
+      fprintf(stderr, "  (block0 start - last start %.2f)  body: %llu shader cycles in %.2f us = %.0f MHz\n",
+              0.01 * (double)(long long)(h[32] - h[0]), h[11], 0.01 * (double)(long long)(h[3] - h[2]),
+              (double)h[11] / (0.01 * (double)(long long)(h[3] - h[2])));
+    }
+  }
+#endif
   switch (K) {
     case 1: return launch_gmm_k<1>(nblk, a, s);
     case 2: return launch_gmm_k<2>(nblk, a, s);

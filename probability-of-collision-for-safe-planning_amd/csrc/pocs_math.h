@@ -31,14 +31,23 @@
 // ----------------------------------------------------------------------------------------
 struct pocs_u32x4 { uint32_t x, y, z, w; };
 
+// a ^ b ^ c: one v_bitop3_b32 on gfx950 (the compiler emits two v_xor_b32 for the plain form)
+POCS_HD uint32_t pocs_xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+
 POCS_HD pocs_u32x4 pocs_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                       uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n0 = pocs_xor3((uint32_t)(p1 >> 32), c1, k0);
+    const uint32_t n2 = pocs_xor3((uint32_t)(p0 >> 32), c3, k1);
     c1 = (uint32_t)p1;
     c3 = (uint32_t)p0;
     c0 = n0;
@@ -183,11 +192,12 @@ POCS_HD void pocs_tables_init(pocs_tables* T) {
   }
 }
 
-// log(m * 2^-53) for an integer 1 <= m <= 2^53: m = 2^e t, t in [1,2); i = top 7 mantissa bits;
-// r = t*invc_i - 1 (one fma, |r| < 2^-7.9); log = (e-53) ln2 + logc_i + log1p(r), log1p by its
-// degree-7 Taylor polynomial (truncation < 2^-59 relative).
-POCS_HD double pocs_log_unit53(uint64_t m, const pocs_tables* T) {
-  union { double d; uint64_t u; } b; b.d = (double)m;            // exact: m <= 2^53
+// log((w + 1) * 2^-32) for a 32-bit word w, i.e. log of a uniform on (0, 1] with 2^32 levels:
+// m = w + 1 = 2^e t, t in [1,2); i = top 7 mantissa bits; r = t*invc_i - 1 (one fma,
+// |r| < 2^-7.9); log = (e-32) ln2 + logc_i + log1p(r), log1p by its degree-7 Taylor polynomial
+// (truncation < 2^-59 relative).
+POCS_HD double pocs_log_unit32(uint32_t w, const pocs_tables* T) {
+  union { double d; uint64_t u; } b; b.d = (double)w + 1.0;      // exact: m <= 2^32
   const int e = (int)(b.u >> 52) - 1023;
   const int i = (int)(b.u >> 45) & 127;
   b.u = (b.u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;   // t
@@ -198,7 +208,7 @@ POCS_HD double pocs_log_unit53(uint64_t m, const pocs_tables* T) {
   p = fma(r, p, 1.0 / 3.0);
   p = fma(r, p, -0.5);
   p = fma(r * r, p, r);                                           // log1p(r)
-  const double dk = (double)(e - 53);
+  const double dk = (double)(e - 32);
   return fma(dk, 6.93147180369123816490e-01, T->lg[i][1]) + fma(dk, 1.90821492927058770002e-10, p);
 }
 
@@ -256,31 +266,29 @@ POCS_HD void pocs_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint
   *spare = a.w;
 }
 
-// Box-Muller pair through the tables (same definition as pocs_normal_pair).
-POCS_HD void pocs_normal_pair_tab(uint32_t w0, uint32_t w1, uint32_t w2, const pocs_tables* T,
-                                  double* n0, double* n1) {
-  const uint64_t a = ((((uint64_t)w1) << 32) | (uint64_t)w0) >> 11;
-  const double rad = sqrt(-2.0 * pocs_log_unit53(a + 1ull, T));
+// Box-Muller pair of the mixture sampler, through the tables: one word for the radius,
+// u = (wr + 1) 2^-32 in (0,1], radius = sqrt(-2 log u) <= sqrt(64 ln 2) < 6.661 (the bound the
+// obstacle culling of k_gmm_step relies on), one word for the angle 2 pi wa 2^-32.
+POCS_HD void pocs_normal_pair_w2(uint32_t wr, uint32_t wa, const pocs_tables* T, double* n0, double* n1) {
+  const double rad = sqrt(-2.0 * pocs_log_unit32(wr, T));
   double sn, cs;
-  pocs_sincos_2pi_u32_tab(w2, T, &sn, &cs);
+  pocs_sincos_2pi_u32_tab(wa, T, &sn, &cs);
   *n0 = rad * cs;
   *n1 = rad * sn;
 }
 
 // The six standard normals and two spare words of a PAIR of mixture samples (2j, 2j+1), from
-// three draws keyed by the pair index j -- no Box-Muller output is thrown away:
-//   slot 0 -> z0, z1 of sample 2j   (+ its spare word)
-//   slot 1 -> z2 of sample 2j, z0 of sample 2j+1   (+ the spare word of sample 2j+1)
-//   slot 2 -> z1, z2 of sample 2j+1
+// TWO draws keyed by the pair index j -- every word is used, no Box-Muller output is thrown away:
+//   slot 0: (x, y) -> z0, z1 of sample 2j      (z, w) -> z2 of sample 2j, z0 of sample 2j+1
+//   slot 1: (x, y) -> z1, z2 of sample 2j+1    z, w  -> the spare words of samples 2j, 2j+1
 POCS_HD void pocs_normal3_pair(uint64_t seed, uint64_t pair, uint32_t waypoint, uint32_t stream,
                                const pocs_tables* T, double za[3], double zb[3], uint32_t* spare_a,
                                uint32_t* spare_b) {
   const pocs_u32x4 a = pocs_draw(seed, pair, waypoint, stream, 0u);
   const pocs_u32x4 b = pocs_draw(seed, pair, waypoint, stream, 1u);
-  const pocs_u32x4 c = pocs_draw(seed, pair, waypoint, stream, 2u);
-  pocs_normal_pair_tab(a.x, a.y, a.z, T, &za[0], &za[1]);
-  pocs_normal_pair_tab(b.x, b.y, b.z, T, &za[2], &zb[0]);
-  pocs_normal_pair_tab(c.x, c.y, c.z, T, &zb[1], &zb[2]);
-  *spare_a = a.w;
+  pocs_normal_pair_w2(a.x, a.y, T, &za[0], &za[1]);
+  pocs_normal_pair_w2(a.z, a.w, T, &za[2], &zb[0]);
+  pocs_normal_pair_w2(b.x, b.y, T, &zb[1], &zb[2]);
+  *spare_a = b.z;
   *spare_b = b.w;
 }

@@ -14,7 +14,7 @@ static const pocs_tables* tabs() {
 }
 
 extern "C" {
-double hh_log_unit53(uint64_t m) { return pocs_log_unit53(m, tabs()); }
+double hh_log_unit32(uint32_t w) { return pocs_log_unit32(w, tabs()); }
 void hh_sincos_tab(double x, double* s, double* c) { pocs_sincos_tab(x, tabs(), s, c); }
 void hh_sincos_2pi_u32_tab(uint32_t w, double* s, double* c) { pocs_sincos_2pi_u32_tab(w, tabs(), s, c); }
 void hh_philox(const uint32_t* c, const uint32_t* k, uint32_t* o) {

@@ -45,21 +45,22 @@ def test_normal3_bitwise(hh, orc):
 def test_table_functions_bitwise_and_accurate(hh, orc):
     """The table-driven log / sincos of the hot path: product == oracle bit for bit, and both
     within ~1 ulp of libm."""
-    hh.hh_log_unit53.restype = C.c_double
-    hh.hh_log_unit53.argtypes = [C.c_uint64]
+    hh.hh_log_unit32.restype = C.c_double
+    hh.hh_log_unit32.argtypes = [C.c_uint32]
     rng = np.random.default_rng(21)
-    ms = [1, 2, 3, 2 ** 53, 2 ** 53 - 1, 2 ** 52, 2 ** 52 + 1] + [int(v) for v in rng.integers(1, 2 ** 53, 20000)] + \
-         [int(v) for v in rng.integers(1, 2 ** 20, 2000)]
+    ws = [0, 1, 2, 2 ** 32 - 1, 2 ** 32 - 2, 2 ** 31, 2 ** 31 - 1] + [int(v) for v in rng.integers(0, 2 ** 32, 20000)] + \
+         [int(v) for v in rng.integers(0, 2 ** 12, 2000)]
     worst = 0.0
-    for m in ms:
-        got = hh.hh_log_unit53(m)
-        assert got == orc.log_unit53(m)
-        want = math.log(m * 2.0 ** -53)            # m * 2^-53 is exact in binary64
+    for w in ws:
+        got = hh.hh_log_unit32(w)
+        assert got == orc.log_unit32(w)
+        want = math.log((w + 1) * 2.0 ** -32)      # (w + 1) * 2^-32 is exact in binary64
         # absolute accuracy (what the radius sqrt(-2 log u) needs); near u = 1 the table form
         # cancels, so its RELATIVE error there is larger than the polynomial form's -- harmless
         worst = max(worst, abs(got - want) / max(abs(want), 1.0))
     assert worst < 3e-16, worst
-    assert abs(hh.hh_log_unit53(2 ** 53)) < 2e-16
+    assert abs(hh.hh_log_unit32(2 ** 32 - 1)) < 2e-16            # u = 1: radius 0
+    assert math.sqrt(-2 * hh.hh_log_unit32(0)) < 6.661           # the bound the obstacle culling uses
     s, c = C.c_double(), C.c_double()
     for x in np.concatenate([rng.uniform(-20, 20, 8000), rng.uniform(-1e4, 1e4, 1000), [0.0, -0.0, 6.283185307179586, 1.5707963267948966]]):
         hh.hh_sincos_tab(C.c_double(x), C.byref(s), C.byref(c))
@@ -74,7 +75,7 @@ def test_table_functions_bitwise_and_accurate(hh, orc):
 
 
 def test_sample_pairs_bitwise(hh, orc):
-    """Mixture samples 2j and 2j+1 share three draws keyed by the pair index j."""
+    """Mixture samples 2j and 2j+1 share two draws keyed by the pair index j."""
     za, zb = (C.c_double * 3)(), (C.c_double * 3)()
     sa, sb = C.c_uint32(), C.c_uint32()
     for pair in list(range(100)) + [2 ** 31 - 1, 2 ** 31, 2 ** 39 + 5]:
@@ -86,7 +87,8 @@ def test_sample_pairs_bitwise(hh, orc):
     z = np.array([orc.sample_normals(5, i, 3)[0] for i in range(30000)])
     assert abs(z.mean()) < 0.02 and abs(z.var() - 1) < 0.02
     assert np.max(np.abs(np.corrcoef(z.T) - np.eye(3))) < 0.02
-    assert abs(np.corrcoef(z[0::2, 2], z[1::2, 0])[0, 1]) < 0.03     # the two halves of slot 1
+    assert abs(np.corrcoef(z[0::2, 2], z[1::2, 0])[0, 1]) < 0.03     # the two halves of one Box-Muller pair
+    assert np.max(np.abs(z)) < 6.661
 
 
 def test_motion_and_wrap_bitwise(hh, orc, plan):
