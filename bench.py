@@ -59,13 +59,14 @@ def cpu_baseline(plan, env, K, W, path, budget_evals):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0,
                     help="independent runs (steps) advanced in lockstep per call (pocs_set_batch); "
-                         "default 16 for the GMM path, 8 for MC (8 x 28 MB of particle state stay in the "
-                         "256 MB Infinity Cache between waypoint launches, 16 x do not)")
+                         "default 64 for the GMM path (the per-launch tail -- reduce, mixture advance, launch gap, "
+                         "~15 us -- is paid once per waypoint for the whole batch), 8 for MC (8 x 28 MB of particle "
+                         "state stay in the 256 MB Infinity Cache between waypoint launches, 16 x do not)")
     ap.add_argument("--samples", type=int, default=0, help="override samples per GPU (experiments only)")
     ap.add_argument("--mc-fused", action="store_true",
                     help="MC workloads: whole roll-out in registers (k_mc_fused, ~0 B/eval) instead of streaming")
@@ -106,7 +107,7 @@ def main():
 
     # K steps are issued as `ncalls` calls of nearly equal batch: `n_hi` calls of b_hi = b_lo + 1
     # runs and the rest of b_lo runs.
-    maxb = args.batch if args.batch > 0 else (16 if path == "gmm" else 8)
+    maxb = args.batch if args.batch > 0 else (64 if path == "gmm" else 8)
     ncalls = (args.steps + maxb - 1) // maxb
     b_lo, n_hi = divmod(args.steps, ncalls)
     b_hi = b_lo + 1 if n_hi else b_lo

@@ -83,8 +83,12 @@ def summary(props, times):
 
 
 def run_experiment(simoption, num_runs=200, num_particles=10000, num_gaussians=3, seed=1, device=0,
-                   plan=None, env=None, envfile=None, params=None, out_dir=".", stamp=None):
-    """MCSimulation.py:221-269.  Returns dict(times, proportions, journal, report, summary)."""
+                   plan=None, env=None, envfile=None, params=None, out_dir=".", stamp=None, batch=1):
+    """MCSimulation.py:221-269.  Returns dict(times, proportions, journal, report, summary).
+
+    batch=1 issues one run per command like the reference.  batch=R (ours) advances R of the
+    independent runs per command in lockstep on the GPU (pocs_set_batch): same runs, same seeds,
+    same journal and report; a run's simTime is then its call's wall time / R."""
     if simoption not in ("MC", "GMM"):
         raise ValueError('simoption must be "MC" or "GMM"')              # MCSimulation.py:108-111
     plan = plan or planio.load_plan()
@@ -101,15 +105,22 @@ def run_experiment(simoption, num_runs=200, num_particles=10000, num_gaussians=3
         push_configuration(mod, plan, env, params, num_particles, simoption, num_gaussians)
         mod.SendCommand("setSeed " + str(int(seed)))
         command = "runSimulation" if simoption == "MC" else "runGMMEstimation"
-        for i in range(num_runs):
+        batch = max(1, int(batch))
+        i = 0
+        while i < num_runs:
+            b = min(batch, num_runs - i)
+            if batch > 1:
+                mod.set_batch(b)
             start = time.perf_counter()
             collprop = float(mod.SendCommand(command))
-            sim_time = time.perf_counter() - start
-            times.append(sim_time)
-            props.append(collprop)
-            f2.write("Simulation: " + str(i) + "\n")
-            f2.write("simTime: " + str(sim_time) + "\n")
-            f2.write("collProp: " + str(collprop) + "\n")
+            sim_time = (time.perf_counter() - start) / b
+            for p in ([collprop] if batch == 1 else [float(v) for v in mod.batch_probabilities()]):
+                times.append(sim_time)
+                props.append(p)
+                f2.write("Simulation: " + str(i) + "\n")
+                f2.write("simTime: " + str(sim_time) + "\n")
+                f2.write("collProp: " + str(p) + "\n")
+                i += 1
             f2.flush()
             os.fsync(f2.fileno())
     write_report(report, simoption, envfile, params, num_runs, num_particles, plan, times, props, num_gaussians)
@@ -125,12 +136,13 @@ def main(argv=None):
     ap.add_argument("--gaussians", type=int, default=3)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=1, help="runs advanced in lockstep per command (1 = like the reference)")
     ap.add_argument("--plan", default=None)
     ap.add_argument("--env", default=None)
     ap.add_argument("--out", default=".")
     a = ap.parse_args(argv)
     r = run_experiment(a.simoption, a.runs, a.particles, a.gaussians, a.seed, a.device,
-                       plan=planio.load_plan(a.plan) if a.plan else None, envfile=a.env, out_dir=a.out)
+                       plan=planio.load_plan(a.plan) if a.plan else None, envfile=a.env, out_dir=a.out, batch=a.batch)
     s = r["summary"]
     print("Average Prob Collision: %.6f  (sd %.6f, range %.4f-%.4f), Average Sim Time: %.6f s"
           % (s["mean"], s["std"], s["min"], s["max"], s["mean_time"]))
