@@ -262,10 +262,9 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
 #if defined(POCS_ABLATE_RNG)          // timing-only builds (tools/ablate.sh): outputs are wrong
     for (int h = 0; h < 2; ++h) { zz[h][0] = (double)(lp & 7) * 0.1; zz[h][1] = (double)(lp & 3) * 0.1; zz[h][2] = 0.05; spare[h] = (uint32_t)lp * 2654435761u; }
 #elif defined(POCS_ABLATE_BOXMULLER)
-    { const pocs_u32x4 A = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 0u), B = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 1u),
-                       Cc = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 2u);
-      zz[0][0] = (double)A.x * 0x1p-32; zz[0][1] = (double)A.y * 0x1p-32; zz[0][2] = (double)A.z * 0x1p-32; spare[0] = A.w;
-      zz[1][0] = (double)B.x * 0x1p-32; zz[1][1] = (double)B.y * 0x1p-32; zz[1][2] = (double)(B.z ^ Cc.x ^ Cc.y ^ Cc.z) * 0x1p-32; spare[1] = B.w; }
+    { const pocs_u32x4 A = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 0u), B = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 1u);
+      zz[0][0] = (double)A.x * 0x1p-32; zz[0][1] = (double)A.y * 0x1p-32; zz[0][2] = (double)A.z * 0x1p-32; spare[0] = B.z;
+      zz[1][0] = (double)A.w * 0x1p-32; zz[1][1] = (double)B.x * 0x1p-32; zz[1][2] = (double)B.y * 0x1p-32; spare[1] = B.w; }
 #else
     pocs_normal3_pair(seed, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, &s_tab, zz[0], zz[1], &spare[0], &spare[1]);
 #endif
@@ -341,10 +340,13 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
     if (STORE) {
       const size_t o = (size_t)r * a.sample_stride + (size_t)i0;      // sample_stride is even
       if (two) {
-        *reinterpret_cast<double2*>(a.x + o) = make_double2(xs[0], xs[1]);
-        *reinterpret_cast<double2*>(a.y + o) = make_double2(ys[0], ys[1]);
-        *reinterpret_cast<double2*>(a.th + o) = make_double2(ts[0], ts[1]);
-        *reinterpret_cast<int*>(a.flags + o) = (hits[0] ? 1 : 0) | (hits[1] ? 0x10000 : 0);
+        // written once, never re-read by the kernels: non-temporal, so the stream does not displace
+        // the tables / partial rows in L2
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store((v2d){xs[0], xs[1]}, reinterpret_cast<v2d*>(a.x + o));
+        __builtin_nontemporal_store((v2d){ys[0], ys[1]}, reinterpret_cast<v2d*>(a.y + o));
+        __builtin_nontemporal_store((v2d){ts[0], ts[1]}, reinterpret_cast<v2d*>(a.th + o));
+        __builtin_nontemporal_store((hits[0] ? 1 : 0) | (hits[1] ? 0x10000 : 0), reinterpret_cast<int*>(a.flags + o));
       } else {
         a.x[o] = xs[0]; a.y[o] = ys[0]; a.th[o] = ts[0];
         a.flags[o] = hits[0] ? (int16_t)1 : (int16_t)0;
