@@ -17,8 +17,8 @@ with pocs_amd.Context(0) as c:
     while time.time() - t0 < budget:
         K = int(rng.integers(1, 9))
         N = int(rng.choice([513, 7777, 65537, 262145, 1000003, 3000001]))
-        R = int(rng.choice([1, 2, 3, 5, 8, 16]))
-        if N * R > 20_000_000:
+        R = int(rng.choice([1, 2, 3, 5, 8, 16, 33, 64]))
+        if N * R > 70_000_000:
             R = 1
         seed = int(rng.integers(0, 2 ** 62))
         c.configure(plan, env, K=K, N=N, seed=seed)
