@@ -74,6 +74,12 @@ def main():
     ap.add_argument("--cpu-evals", type=float, default=6.0e7, help="size of the CPU baseline sample")
     args = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: libraries that write to fd 1 (RCCL prints
+    # a version banner at communicator creation) go to stderr until the line is printed
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import pocs_amd
     par = import_module("probability-of-collision-for-safe-planning_amd.parallel")
@@ -236,7 +242,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(plan, env, K, W, path, args.cpu_evals)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     for c, _ in made:
         c.close()
     if dist is not None:

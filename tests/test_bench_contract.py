@@ -10,11 +10,12 @@ ROOT = Path(__file__).resolve().parents[1]
 pytestmark = pytest.mark.gpu
 
 
-def run_bench(*extra):
+def run_bench(*extra, env=None):
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "5", "--warmup", "2", "--samples", "20000",
-                          "--cpu-evals", "2e5", *extra], capture_output=True, text=True, check=True, cwd=str(ROOT))
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+                          "--cpu-evals", "2e5", *extra], capture_output=True, text=True, check=True, cwd=str(ROOT),
+                         env=env)
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout            # ONE line on stdout, nothing else (library banners go to stderr)
     return json.loads(lines[0])
 
 
@@ -39,3 +40,13 @@ def test_default_line_has_every_field():
 def test_mc_workload_line():
     d = run_bench("--workload", "mc", "--no-cpu-baseline")
     assert "MC" in d["metric"] and d["roofline"]["bytes_per_eval"] == 56 and "cpu_baseline" not in d
+
+
+def test_sharded_path_on_one_rank_prints_one_line():
+    """The N>1 code path (torch.distributed over RCCL, per-waypoint all-reduce, two engines)
+    rehearsed with world size 1: same contract, and RCCL's banner must not reach stdout."""
+    import os
+    env = dict(os.environ, POCS_FORCE_SHARDED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    d = run_bench("--no-cpu-baseline", env=env)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and sum(d["config"]["calls"]) == 5
