@@ -266,11 +266,33 @@ POCS_HD void pocs_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint
   *spare = a.w;
 }
 
+// sqrt for 0 <= t <= 64 (the squared Box-Muller radius), correctly rounded like sqrt().  On the
+// device: the compiler's own f64 expansion (v_rsq_f64 seed, one coupled Goldschmidt step, two
+// residual corrections) without the 2^+-256 range scaling it wraps around it for arguments below
+// 2^-767, which cannot occur here; sqrt(+-0) = +-0 is selected explicitly (rsq(0) = inf).
+POCS_HD double pocs_sqrt_radius2(double t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rsq(t);
+  double g = t * y;
+  double h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, t);
+  g = fma(d, h, g);
+  d = fma(-g, g, t);
+  g = fma(d, h, g);
+  return (t == 0.0) ? t : g;
+#else
+  return sqrt(t);
+#endif
+}
+
 // Box-Muller pair of the mixture sampler, through the tables: one word for the radius,
 // u = (wr + 1) 2^-32 in (0,1], radius = sqrt(-2 log u) <= sqrt(64 ln 2) < 6.661 (the bound the
 // obstacle culling of k_gmm_step relies on), one word for the angle 2 pi wa 2^-32.
 POCS_HD void pocs_normal_pair_w2(uint32_t wr, uint32_t wa, const pocs_tables* T, double* n0, double* n1) {
-  const double rad = sqrt(-2.0 * pocs_log_unit32(wr, T));
+  const double rad = pocs_sqrt_radius2(-2.0 * pocs_log_unit32(wr, T));
   double sn, cs;
   pocs_sincos_2pi_u32_tab(wa, T, &sn, &cs);
   *n0 = rad * cs;

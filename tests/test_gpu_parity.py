@@ -75,6 +75,21 @@ def test_gmm_first_waypoint_samples_bit_exact(ctx, orc, plan, env):
     assert abs(p - want["prob"]) < 1e-15
 
 
+def test_gmm_two_million_samples_bit_exact(ctx, orc, plan, env):
+    """Same at N = 2*10^6 (3*10^6 Box-Muller radii through the device's own sqrt sequence,
+    pocs_sqrt_radius2, against the host's correctly rounded sqrt)."""
+    one = dict(traj=plan["traj"][:1], odom=plan["odom"][:0])
+    cfg = orc.config(one, env, K=2)
+    N = 2_000_000
+    ctx.configure(one, env, K=2, N=N, seed=SEED + 99)
+    ctx.run_gmm_estimation()
+    want = orc.run_gmm(cfg, SEED + 99, N, want_samples=True)
+    xyz, flags = ctx.gmm_samples(N)
+    assert np.array_equal(flags, want["flags"])
+    assert np.array_equal(xyz, want["samples"])
+    assert np.array_equal(ctx.moments(0, 2)[:, :2], want["moments"][0][:, :2])
+
+
 @pytest.mark.parametrize("K,N", [(1, 3000), (3, 10000), (8, 6000), (3, 100)])
 def test_gmm_matches_oracle(ctx, orc, plan, env, K, N):
     cfg = orc.config(plan, env, K=K)
