@@ -256,7 +256,15 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   const long long stride = (long long)gridDim.x * POCS_GMM_BLOCK;
   const long long npairs = (a.count + 1) >> 1;
   const uint64_t pair0 = (uint64_t)(a.first >> 1);
-  for (long long lp = (long long)blockIdx.x * POCS_GMM_BLOCK + tid; lp < npairs; lp += stride) {
+  // The loop counter is wave-uniform (SGPRs) and the lane adds its tid: the store addresses are a
+  // scalar base per iteration plus a constant 16*tid, no per-lane 64-bit address arithmetic.
+  double* const xr = a.x + (size_t)r * a.sample_stride;          // this run's slice (sample_stride is even)
+  double* const yr = a.y + (size_t)r * a.sample_stride;
+  double* const tr = a.th + (size_t)r * a.sample_stride;
+  int16_t* const fr = a.flags + (size_t)r * a.sample_stride;
+  for (long long base = (long long)blockIdx.x * POCS_GMM_BLOCK; base < npairs; base += stride) {
+    const long long lp = base + tid;
+    if (lp >= npairs) continue;
     double zz[2][3];
     uint32_t spare[2];
 #if defined(POCS_ABLATE_RNG)          // timing-only builds (tools/ablate.sh): outputs are wrong
@@ -338,19 +346,16 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
 #endif
     }
     if (STORE) {
-      const size_t o = (size_t)r * a.sample_stride + (size_t)i0;      // sample_stride is even
-      if (two) {
-        // written once, never re-read by the kernels: non-temporal, so the stream does not displace
-        // the tables / partial rows in L2
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        __builtin_nontemporal_store((v2d){xs[0], xs[1]}, reinterpret_cast<v2d*>(a.x + o));
-        __builtin_nontemporal_store((v2d){ys[0], ys[1]}, reinterpret_cast<v2d*>(a.y + o));
-        __builtin_nontemporal_store((v2d){ts[0], ts[1]}, reinterpret_cast<v2d*>(a.th + o));
-        __builtin_nontemporal_store((hits[0] ? 1 : 0) | (hits[1] ? 0x10000 : 0), reinterpret_cast<int*>(a.flags + o));
-      } else {
-        a.x[o] = xs[0]; a.y[o] = ys[0]; a.th[o] = ts[0];
-        a.flags[o] = hits[0] ? (int16_t)1 : (int16_t)0;
-      }
+      // Both poses of the pair leave together.  For the last sample of an odd shard the second
+      // slot is the pair's unused twin: it lands in the padding element of the run's slice
+      // (sample_stride >= count + 1 then) and is never read back.  Written once, never re-read by
+      // the kernels: non-temporal, so the stream does not displace the tables / partial rows in L2.
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      const size_t ub = 2 * (size_t)base;
+      __builtin_nontemporal_store((v2d){xs[0], xs[1]}, reinterpret_cast<v2d*>(xr + ub) + tid);
+      __builtin_nontemporal_store((v2d){ys[0], ys[1]}, reinterpret_cast<v2d*>(yr + ub) + tid);
+      __builtin_nontemporal_store((v2d){ts[0], ts[1]}, reinterpret_cast<v2d*>(tr + ub) + tid);
+      __builtin_nontemporal_store((hits[0] ? 1 : 0) | ((two && hits[1]) ? 0x10000 : 0), reinterpret_cast<int*>(fr + ub) + tid);
     }
   }
 
