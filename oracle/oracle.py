@@ -78,6 +78,11 @@ class Oracle:
     def log_unit32(self, w):
         return self.lib.orc_log_unit32(C.c_uint32(w))
 
+    def normal_pair_w2(self, wr, wa):
+        a, b = C.c_double(), C.c_double()
+        self.lib.orc_normal_pair_w2(C.c_uint32(wr), C.c_uint32(wa), C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def sincos_tab(self, x):
         s, c = C.c_double(), C.c_double()
         self.lib.orc_sincos_tab(C.c_double(x), C.byref(s), C.byref(c))

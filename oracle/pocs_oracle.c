@@ -186,20 +186,20 @@ void orc_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stre
 }
 
 /* ---- table-driven forms (hot path: mixture samples, footprint heading) ------------------------
- * lg[i] = {1/c_i rounded, -log(that)}, c_i = 1 + (i + 1/2)/128; sc[s] = {cos, sin} of the centre of
- * sector s of 64.  Built from the functions above, on first use. */
-static double tab_lg[128][2], tab_sc[64][2];
+ * lg[i] = {1/c_i rounded, -log(that)}, c_i = 1 + (i + 1/2)/512; sc[s] = {cos, sin} of the centre of
+ * sector s of 256.  Built from the functions above, on first use. */
+static double tab_lg[512][2], tab_sc[256][2];
 static int tab_ready = 0;
 static void tables(void) {
   if (tab_ready) return;
-  for (int i = 0; i < 128; ++i) {
-    double c = 1.0 + ((double)i + 0.5) / 128.0;
+  for (int i = 0; i < 512; ++i) {
+    double c = 1.0 + ((double)i + 0.5) / 512.0;
     tab_lg[i][0] = 1.0 / c;
     tab_lg[i][1] = -orc_log(tab_lg[i][0]);
   }
-  for (int s = 0; s < 64; ++s) {
+  for (int s = 0; s < 256; ++s) {
     double sn, cs;
-    orc_sincos_2pi_u32(((uint32_t)s << 26) + (1u << 25), &sn, &cs);
+    orc_sincos_2pi_u32(((uint32_t)s << 24) + (1u << 23), &sn, &cs);
     tab_sc[s][0] = cs; tab_sc[s][1] = sn;
   }
   tab_ready = 1;
@@ -211,14 +211,14 @@ double orc_log_unit32(uint32_t w) {   /* log((w + 1) 2^-32): a uniform on (0, 1]
   uint64_t bits;
   memcpy(&bits, &x, 8);
   int e = (int)(bits >> 52) - 1023;
-  int i = (int)((bits >> 45) & 127);
+  int i = (int)((bits >> 43) & 511);
   bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
   double t;
   memcpy(&t, &bits, 8);
   double r = fma(t, tab_lg[i][0], -1.0);
-  static const double co[6] = {-0.5, 1.0 / 3.0, -1.0 / 4.0, 1.0 / 5.0, -1.0 / 6.0, 1.0 / 7.0};
-  double p = co[5];
-  for (int k = 4; k >= 0; --k) p = fma(r, p, co[k]);
+  static const double co[4] = {-0.5, 1.0 / 3.0, -1.0 / 4.0, 1.0 / 5.0};
+  double p = co[3];
+  for (int k = 2; k >= 0; --k) p = fma(r, p, co[k]);
   double l1p = fma(r * r, p, r);
   double dk = (double)(e - 32);
   return fma(dk, 6.93147180369123816490e-01, tab_lg[i][1]) + fma(dk, 1.90821492927058770002e-10, l1p);
@@ -226,20 +226,18 @@ double orc_log_unit32(uint32_t w) {   /* log((w + 1) 2^-32): a uniform on (0, 1]
 
 static void sincos_small(double d, double* sd, double* cd) {
   double z = d * d;
-  double ps = fma(z, -1.0 / 5040.0, 1.0 / 120.0);
-  ps = fma(z, ps, -1.0 / 6.0);
+  double ps = fma(z, 1.0 / 120.0, -1.0 / 6.0);           /* |d| <= pi/256: next terms < 1e-17 */
   *sd = fma(d * z, ps, d);
-  double pc = fma(z, 1.0 / 40320.0, -1.0 / 720.0);
-  pc = fma(z, pc, 1.0 / 24.0);
+  double pc = fma(z, -1.0 / 720.0, 1.0 / 24.0);
   pc = fma(z, pc, -0.5);
   *cd = fma(z, pc, 1.0);
 }
 
 void orc_sincos_2pi_u32_tab(uint32_t w, double* s, double* c) {
   tables();
-  int sec = (int)(w >> 26);
-  int f = (int)(w & 0x03ffffffu) - (1 << 25);
-  double d = (double)f * ((1.0 / 67108864.0) * 9.81747704246810387019e-02);
+  int sec = (int)(w >> 24);
+  int f = (int)(w & 0x00ffffffu) - (1 << 23);
+  double d = (double)f * ((1.0 / 16777216.0) * 2.45436926061702587187e-02);   /* 2 pi / 256 */
   double sd, cd;
   sincos_small(d, &sd, &cd);
   double C = tab_sc[sec][0], S = tab_sc[sec][1];
@@ -249,14 +247,14 @@ void orc_sincos_2pi_u32_tab(uint32_t w, double* s, double* c) {
 
 void orc_sincos_tab(double x, double* s, double* c) {
   tables();
-  double fn = floor(x * 1.01859163578813017e+01);
+  double fn = floor(x * 4.07436654315252084757e+01);      /* 256 / (2 pi) */
   int n = (int)fn;
-  double d = fma(-fn, 9.81747704208828509e-02, x);
-  d = fma(-fn, 3.79818781643997874e-12, d);
-  d = fma(-fn, 1.26391640549746914e-22, d);
+  double d = fma(-fn, 2.45436926052207127213e-02, x);     /* pi/128 in three pieces */
+  d = fma(-fn, 9.49546954109994683843e-13, d);
+  d = fma(-fn, 3.15979101374367286178e-23, d);
   double sd, cd;
-  sincos_small(d - 4.90873852123405193510e-02, &sd, &cd);
-  int sec = n & 63;
+  sincos_small(d - 1.22718463030851293594e-02, &sd, &cd); /* half a sector */
+  int sec = n & 255;
   double C = tab_sc[sec][0], S = tab_sc[sec][1];
   *s = fma(S, cd, C * sd);
   *c = fma(C, cd, -(S * sd));
@@ -264,7 +262,7 @@ void orc_sincos_tab(double x, double* s, double* c) {
 
 /* Box-Muller pair of the mixture sampler: radius word wr, angle word wa. */
 void orc_normal_pair_w2(uint32_t wr, uint32_t wa, double* n0, double* n1) {
-  double radius = sqrt(-2.0 * orc_log_unit32(wr));
+  double radius = sqrt(fabs(-2.0 * orc_log_unit32(wr)));   /* |.|: at u = 1 the log may be a rounding error above 0 */
   double s, c;
   orc_sincos_2pi_u32_tab(wa, &s, &c);
   *n0 = radius * c;

@@ -166,45 +166,44 @@ POCS_HD void pocs_normal_pair(uint32_t w0, uint32_t w1, uint32_t w2, double* n0,
 
 // ----------------------------------------------------------------------------------------
 // Table-driven forms used on the hot path (mixture samples, footprint heading): the same
-// functions to ~1 ulp with less than half the instructions.  The 3 KB of tables are built once
+// functions to ~1 ulp with less than half the instructions.  The 12 KB of tables are built once
 // on the host FROM THE FUNCTIONS ABOVE (so product and oracle, whose functions agree bit for
 // bit, build identical tables) and staged in LDS by the kernels.
-//   lg[i] = {invc_i, logc_i}, c_i = 1 + (i + 1/2)/128:  invc_i = 1/c_i rounded, logc_i = -log(invc_i)
-//   sc[s] = {cos, sin} of the centre of sector s of 64: angle 2 pi (s + 1/2)/64
+//   lg[i] = {invc_i, logc_i}, c_i = 1 + (i + 1/2)/512:  invc_i = 1/c_i rounded, logc_i = -log(invc_i)
+//   sc[s] = {cos, sin} of the centre of sector s of 256: angle 2 pi (s + 1/2)/256
+// (12 KB; v4 had 128 / 64 entries and two more polynomial terms in each of log, sin and cos)
 // ----------------------------------------------------------------------------------------
 struct pocs_tables {
-  double lg[128][2];
-  double sc[64][2];
+  double lg[512][2];
+  double sc[256][2];
 };
 
 POCS_HD void pocs_tables_init(pocs_tables* T) {
-  for (int i = 0; i < 128; ++i) {
-    const double c = 1.0 + ((double)i + 0.5) * 0x1p-7;
+  for (int i = 0; i < 512; ++i) {
+    const double c = 1.0 + ((double)i + 0.5) * 0x1p-9;
     const double invc = 1.0 / c;
     T->lg[i][0] = invc;
     T->lg[i][1] = -pocs_log(invc);
   }
-  for (int s = 0; s < 64; ++s) {
+  for (int s = 0; s < 256; ++s) {
     double sn, cs;
-    pocs_sincos_2pi_u32(((uint32_t)s << 26) + (1u << 25), &sn, &cs);
+    pocs_sincos_2pi_u32(((uint32_t)s << 24) + (1u << 23), &sn, &cs);
     T->sc[s][0] = cs;
     T->sc[s][1] = sn;
   }
 }
 
 // log((w + 1) * 2^-32) for a 32-bit word w, i.e. log of a uniform on (0, 1] with 2^32 levels:
-// m = w + 1 = 2^e t, t in [1,2); i = top 7 mantissa bits; r = t*invc_i - 1 (one fma,
-// |r| < 2^-7.9); log = (e-32) ln2 + logc_i + log1p(r), log1p by its degree-7 Taylor polynomial
-// (truncation < 2^-59 relative).
+// m = w + 1 = 2^e t, t in [1,2); i = top 9 mantissa bits; r = t*invc_i - 1 (one fma,
+// |r| < 2^-9.9); log = (e-32) ln2 + logc_i + log1p(r), log1p by its degree-5 Taylor polynomial
+// (truncation < 2^-62 absolute).
 POCS_HD double pocs_log_unit32(uint32_t w, const pocs_tables* T) {
   union { double d; uint64_t u; } b; b.d = (double)w + 1.0;      // exact: m <= 2^32
   const int e = (int)(b.u >> 52) - 1023;
-  const int i = (int)(b.u >> 45) & 127;
+  const int i = (int)(b.u >> 43) & 511;
   b.u = (b.u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;   // t
   const double r = fma(b.d, T->lg[i][0], -1.0);
-  double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
-  p = fma(r, p, 1.0 / 5.0);
-  p = fma(r, p, -1.0 / 4.0);
+  double p = fma(r, 1.0 / 5.0, -1.0 / 4.0);
   p = fma(r, p, 1.0 / 3.0);
   p = fma(r, p, -0.5);
   p = fma(r * r, p, r);                                           // log1p(r)
@@ -212,23 +211,21 @@ POCS_HD double pocs_log_unit32(uint32_t w, const pocs_tables* T) {
   return fma(dk, 6.93147180369123816490e-01, T->lg[i][1]) + fma(dk, 1.90821492927058770002e-10, p);
 }
 
-// sin / cos of a small angle |d| <= pi/64 (Taylor to d^7 / d^8: truncation < 1 ulp)
+// sin / cos of a small angle |d| <= pi/256 (Taylor to d^5 / d^6: truncation < 1e-17)
 POCS_HD void pocs_sincos_small(double d, double* sd, double* cd) {
   const double z = d * d;
-  double ps = fma(z, -1.0 / 5040.0, 1.0 / 120.0);
-  ps = fma(z, ps, -1.0 / 6.0);
+  const double ps = fma(z, 1.0 / 120.0, -1.0 / 6.0);
   *sd = fma(d * z, ps, d);
-  double pc = fma(z, 1.0 / 40320.0, -1.0 / 720.0);
-  pc = fma(z, pc, 1.0 / 24.0);
+  double pc = fma(z, -1.0 / 720.0, 1.0 / 24.0);
   pc = fma(z, pc, -0.5);
   *cd = fma(z, pc, 1.0);
 }
 
-// sin and cos of 2 pi w 2^-32: sector = top 6 bits, d = offset from the sector centre.
+// sin and cos of 2 pi w 2^-32: sector = top 8 bits, d = offset from the sector centre.
 POCS_HD void pocs_sincos_2pi_u32_tab(uint32_t w, const pocs_tables* T, double* sn, double* cs) {
-  const int s = (int)(w >> 26);
-  const int f = (int)(w & 0x03ffffffu) - (1 << 25);                       // [-2^25, 2^25)
-  const double d = (double)f * (0x1p-26 * 9.81747704246810387019e-02);    // 2 pi / 64 per sector
+  const int s = (int)(w >> 24);
+  const int f = (int)(w & 0x00ffffffu) - (1 << 23);                       // [-2^23, 2^23)
+  const double d = (double)f * (0x1p-24 * 2.45436926061702587187e-02);    // 2 pi / 256 per sector
   double sd, cd;
   pocs_sincos_small(d, &sd, &cd);
   const double C = T->sc[s][0], S = T->sc[s][1];
@@ -236,19 +233,19 @@ POCS_HD void pocs_sincos_2pi_u32_tab(uint32_t w, const pocs_tables* T, double* s
   *cs = fma(C, cd, -(S * sd));
 }
 
-// sin and cos of an arbitrary angle |x| < 2^20 by the same sectors: n = floor(x * 64/(2 pi)),
-// d = x - n * (2 pi / 64) in three Cody-Waite steps (33 + 33 + 53 bit split of pi/32), then the
-// offset from the centre of sector n mod 64.
+// sin and cos of an arbitrary angle |x| < 2^18 by the same sectors: n = floor(x * 256/(2 pi)),
+// d = x - n * (2 pi / 256) in three Cody-Waite steps (33 + 33 + 53 bit split of pi/128), then the
+// offset from the centre of sector n mod 256.
 POCS_HD void pocs_sincos_tab(double x, const pocs_tables* T, double* sn, double* cs) {
-  const double fn = floor(x * 1.01859163578813017e+01);
+  const double fn = floor(x * 4.07436654315252084757e+01);
   const int n = (int)fn;
-  double d = fma(-fn, 9.81747704208828509e-02, x);    // pi/32, first 33 bits (fn * it is exact)
-  d = fma(-fn, 3.79818781643997874e-12, d);           // next 33 bits
-  d = fma(-fn, 1.26391640549746914e-22, d);           // tail
-  // sector centres sit at (s + 1/2) * pi/32: shift by half a sector
+  double d = fma(-fn, 2.45436926052207127213e-02, x);    // pi/128, first 33 bits (fn * it is exact)
+  d = fma(-fn, 9.49546954109994683843e-13, d);           // next 33 bits
+  d = fma(-fn, 3.15979101374367286178e-23, d);           // tail
+  // sector centres sit at (s + 1/2) * pi/128: shift by half a sector
   double sd, cd;
-  pocs_sincos_small(d - 4.90873852123405193510e-02, &sd, &cd);
-  const int s = n & 63;
+  pocs_sincos_small(d - 1.22718463030851293594e-02, &sd, &cd);
+  const int s = n & 255;
   const double C = T->sc[s][0], S = T->sc[s][1];
   *sn = fma(S, cd, C * sd);
   *cs = fma(C, cd, -(S * sd));
@@ -292,7 +289,9 @@ POCS_HD double pocs_sqrt_radius2(double t) {
 // u = (wr + 1) 2^-32 in (0,1], radius = sqrt(-2 log u) <= sqrt(64 ln 2) < 6.661 (the bound the
 // obstacle culling of k_gmm_step relies on), one word for the angle 2 pi wa 2^-32.
 POCS_HD void pocs_normal_pair_w2(uint32_t wr, uint32_t wa, const pocs_tables* T, double* n0, double* n1) {
-  const double rad = pocs_sqrt_radius2(-2.0 * pocs_log_unit32(wr, T));
+  // |.|: at u = 1 (wr = 2^32 - 1) the table form of log may land a rounding error (1e-19) ABOVE
+  // zero; the radius is then ~1e-9 instead of 0, never the square root of a negative number
+  const double rad = pocs_sqrt_radius2(fabs(-2.0 * pocs_log_unit32(wr, T)));
   double sn, cs;
   pocs_sincos_2pi_u32_tab(wa, T, &sn, &cs);
   *n0 = rad * cs;

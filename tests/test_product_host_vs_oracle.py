@@ -74,6 +74,26 @@ def test_table_functions_bitwise_and_accurate(hh, orc):
         assert abs(s.value ** 2 + c.value ** 2 - 1.0) < 6e-16
 
 
+def test_box_muller_radius_edge_words(hh, orc):
+    """Every radius word gives finite normals, bit-identical on both sides -- in particular
+    w = 2^32 - 1 (u = 1), where the table form of log may round to a value above zero, and the
+    words whose mantissa sits on a table-interval boundary."""
+    a, b = C.c_double(), C.c_double()
+    rng = np.random.default_rng(5)
+    words = [2 ** 32 - 1 - j for j in range(64)] + list(range(64))
+    words += [(1 << e) + (i << max(e - 9, 0)) - d for e in range(10, 32) for i in (0, 1, 255, 511) for d in (0, 1, 2)]
+    words += [int(v) for v in rng.integers(0, 2 ** 32, 5000)]
+    for wr in words:
+        wr &= 0xFFFFFFFF
+        for wa in (0, 0x40000000, 0x12345678, 0xFFFFFFFF):
+            hh.hh_normal_pair_w2(C.c_uint32(wr), C.c_uint32(wa), C.byref(a), C.byref(b))
+            assert math.isfinite(a.value) and math.isfinite(b.value), (wr, wa)
+            assert (a.value, b.value) == orc.normal_pair_w2(wr, wa), (wr, wa)
+            assert a.value ** 2 + b.value ** 2 < 6.661 ** 2
+    hh.hh_normal_pair_w2(C.c_uint32(2 ** 32 - 1), C.c_uint32(123), C.byref(a), C.byref(b))
+    assert abs(a.value) < 1e-8 and abs(b.value) < 1e-8           # u = 1: radius 0 up to the log's rounding
+
+
 def test_sample_pairs_bitwise(hh, orc):
     """Mixture samples 2j and 2j+1 share two draws keyed by the pair index j."""
     za, zb = (C.c_double * 3)(), (C.c_double * 3)()
