@@ -154,16 +154,16 @@ int grid_blocks(long long count, int block, int default_bpc) {
 // k_gmm_step: blocks PER RUN.  One run alone takes one block per CU (256 partial rows); a batch of
 // R runs shares the chip, so each run gets ~target/R blocks (fewer, fatter blocks: head, tail and
 // partial rows are amortised over more samples).  POCS_GRID_TARGET overrides the total for sweeps.
-int grid_for(long long count, int runs = 1) {
+int grid_for(long long count, int runs, int K) {
   static int target = -1;
   if (target < 0) {
     const char* e = getenv("POCS_GRID_TARGET");
     target = e ? atoi(e) : 0;
     if (target < 0 || target > 8192) target = 0;
   }
-  const int one = grid_blocks(count, POCS_GMM_BLOCK, 1);
+  const int one = grid_blocks(count, POCS_GMM_BLOCK_OF(K), 1);
   if (runs <= 1) return one;
-  int per = (target ? target : 256) / runs;      // floor: never more than one 8-wave block per CU in all
+  int per = (target ? target : 256) / runs;      // floor: never more than one block per CU in all
   if (per < 8) per = 8;
   return per < one ? per : one;
 }
@@ -369,7 +369,7 @@ int gmm_prepare(pocs_ctx* c) {
   if (int r = gmm_shard(c, &first, &count)) return r;
   if (int r = upload_static(c)) return r;
   const size_t W = (size_t)c->W, K = (size_t)c->K, R = (size_t)c->batch;
-  const int nblk = grid_for(count, c->batch);
+  const int nblk = grid_for(count, c->batch, c->K);
   if (int r = ensure(c, c->d_hdr, R * sizeof(pocs_run_header))) return r;
   if (int r = ensure(c, c->d_chain, R * (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE * sizeof(double))) return r;
   if (int r = ensure(c, c->d_state, R * W * K * POCS_STATE_STRIDE * sizeof(double))) return r;
@@ -510,7 +510,7 @@ int enqueue_ticket_reset(pocs_ctx* c) {
 }
 
 int enqueue_gmm_all(pocs_ctx* c, long long first, long long count, bool prof) {
-  const int W = c->W, nblk = grid_for(count, c->batch);
+  const int W = c->W, nblk = grid_for(count, c->batch, c->K);
   if (int r = enqueue_ticket_reset(c)) return r;
   if (int r = enqueue_advance(c, 0)) return r;
   for (int w = 0; w < W; ++w)
@@ -1020,7 +1020,7 @@ int pocs_gmm_step_local(pocs_ctx* c, int w) {
   long long first, count;
   if (int r = gmm_shard(c, &first, &count)) return r;
   if (int r = enqueue_advance(c, w)) return r;        // folds the (reduced) moments of w-1
-  if (int r = enqueue_step(c, grid_for(count, c->batch), first, count, w, false, c->opt_profile ? w : -1)) return r;
+  if (int r = enqueue_step(c, grid_for(count, c->batch, c->K), first, count, w, false, c->opt_profile ? w : -1)) return r;
   c->last_gmm_wp = w;
   c->last_gmm_count = count;
   return POCS_OK;

@@ -95,20 +95,6 @@ __device__ __forceinline__ double load_wt(const double* p) {
       reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// Thread-private moment sums kept in LDS (K <= POCS_LDS_ACC_MAXK): the add runs in the LDS unit
-// (ds_add_f64, IEEE round-to-nearest like v_add_f64), off the FP64 VALU pipe that bounds the
-// kernel, and a sample touches only its own component's nine sums instead of all 9 K.
-#ifndef POCS_LDS_ACC_MAXK
-#define POCS_LDS_ACC_MAXK 0        // off: measured neutral; 3 = K <= 3 (36 KB per component)
-#endif
-__device__ __forceinline__ void lds_add_f64(double* p, double v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)p, v);
-#else
-  *p += v;
-#endif
-}
-
 // Mixture bookkeeping of waypoint `w` (see pocs_gmm_advance_component), run by ONE wave: all 64
 // lanes first pull every input (state[w-1], moments[w-1], the chain record of step w-1, the
 // sensor) into LDS in one round trip, lanes < K then take one component each, lane 0 normalises,
@@ -165,19 +151,17 @@ __device__ unsigned long long g_phase[64];
 #define POCS_PHASE(i) do { } while (0)
 #endif
 
-template <int K, bool STORE>
-__global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) {
+template <int K, bool STORE, int TB>
+__global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
 #if defined(POCS_TRACE_PHASES)
   unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   POCS_PHASE(0);
   constexpr int NC = K * POCS_NMOM;
-  constexpr bool LDSACC = (K <= POCS_LDS_ACC_MAXK);
-  __shared__ double s_acc[LDSACC ? K * 9 * POCS_GMM_BLOCK : 1];     // [k][j][tid]
   __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
   __shared__ double s_par[K * POCS_PARAM_STRIDE];
-  __shared__ double s_red[POCS_GMM_BLOCK / 16][NC];     // one row of sums per 16-lane DPP row
-  __shared__ double s_part[POCS_GMM_BLOCK];
+  __shared__ double s_red[TB / 16][NC];     // one row of sums per 16-lane DPP row
+  __shared__ double s_part[TB];
   __shared__ double s_adv[POCS_ADV_SCRATCH(K)];
   __shared__ double s_keep[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
   __shared__ pocs_tables s_tab;
@@ -192,23 +176,18 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
 
   // ---- head: stage the tables, the obstacle table and this waypoint's sampler parameters in LDS
   stage_tables(a.tables, &s_tab);
-  for (int j = tid; j < M * POCS_OBS_STRIDE; j += POCS_GMM_BLOCK) s_obs[j] = a.env->obs[j];
-  for (int j = tid; j < K * POCS_PARAM_STRIDE; j += POCS_GMM_BLOCK)
+  for (int j = tid; j < M * POCS_OBS_STRIDE; j += TB) s_obs[j] = a.env->obs[j];
+  for (int j = tid; j < K * POCS_PARAM_STRIDE; j += TB)
     s_par[j] = a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j];
   const uint64_t seed = a.hdr[r].seed;
 
-  double acc[LDSACC ? 1 : K][9];
+  double acc[K][9];
   unsigned nfree[K], ncoll[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     nfree[k] = 0u; ncoll[k] = 0u;
-    if (LDSACC) {
 #pragma unroll
-      for (int j = 0; j < 9; ++j) s_acc[(k * 9 + j) * POCS_GMM_BLOCK + tid] = 0.0;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 9; ++j) acc[k][j] = 0.0;
-    }
+    for (int j = 0; j < 9; ++j) acc[k][j] = 0.0;
   }
   __syncthreads();
   POCS_PHASE(1);
@@ -253,7 +232,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   // ---- body: one PAIR of samples (2j, 2j+1) per thread and iteration -- the pair shares two
   // Philox draws = three Box-Muller pairs (pocs_normal3_pair) and its poses leave as 16-byte stores.
   // a.first is even (checked by the host), so local sample 2*lp is global sample first + 2*lp.
-  const long long stride = (long long)gridDim.x * POCS_GMM_BLOCK;
+  const long long stride = (long long)gridDim.x * TB;
   const long long npairs = (a.count + 1) >> 1;
   const uint64_t pair0 = (uint64_t)(a.first >> 1);
   // The loop counter is wave-uniform (SGPRs) and the lane adds its tid: the store addresses are a
@@ -262,7 +241,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   double* const yr = a.y + (size_t)r * a.sample_stride;
   double* const tr = a.th + (size_t)r * a.sample_stride;
   int16_t* const fr = a.flags + (size_t)r * a.sample_stride;
-  for (long long base = (long long)blockIdx.x * POCS_GMM_BLOCK; base < npairs; base += stride) {
+  for (long long base = (long long)blockIdx.x * TB; base < npairs; base += stride) {
     const long long lp = base + tid;
     if (lp >= npairs) continue;
     double zz[2][3];
@@ -306,42 +285,21 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
       acc[0][0] += x + y + t; nfree[0] += hit ? 0u : 1u; ncoll[0] += (valid && k == 0) ? 1u : 0u;
 #else
       const double xx = x * x, xy = x * y, xt = x * t, yy = y * y, yt = y * t, tt = t * t;
-      if (LDSACC) {
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) {
-          const bool sel = valid && (k == kk);
-          nfree[kk] += (sel && !hit) ? 1u : 0u;
-          ncoll[kk] += (sel && hit) ? 1u : 0u;
-        }
-        if (valid && !hit) {
-          double* q = &s_acc[k * (9 * POCS_GMM_BLOCK) + tid];
-          lds_add_f64(q + 0 * POCS_GMM_BLOCK, x);
-          lds_add_f64(q + 1 * POCS_GMM_BLOCK, y);
-          lds_add_f64(q + 2 * POCS_GMM_BLOCK, t);
-          lds_add_f64(q + 3 * POCS_GMM_BLOCK, xx);
-          lds_add_f64(q + 4 * POCS_GMM_BLOCK, xy);
-          lds_add_f64(q + 5 * POCS_GMM_BLOCK, xt);
-          lds_add_f64(q + 6 * POCS_GMM_BLOCK, yy);
-          lds_add_f64(q + 7 * POCS_GMM_BLOCK, yt);
-          lds_add_f64(q + 8 * POCS_GMM_BLOCK, tt);
-        }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) {
-          const bool sel = valid && (k == kk);
-          nfree[kk] += (sel && !hit) ? 1u : 0u;
-          ncoll[kk] += (sel && hit) ? 1u : 0u;
-          const double ind = (sel && !hit) ? 1.0 : 0.0;
-          acc[kk][0] = fma(ind, x, acc[kk][0]);
-          acc[kk][1] = fma(ind, y, acc[kk][1]);
-          acc[kk][2] = fma(ind, t, acc[kk][2]);
-          acc[kk][3] = fma(ind, xx, acc[kk][3]);
-          acc[kk][4] = fma(ind, xy, acc[kk][4]);
-          acc[kk][5] = fma(ind, xt, acc[kk][5]);
-          acc[kk][6] = fma(ind, yy, acc[kk][6]);
-          acc[kk][7] = fma(ind, yt, acc[kk][7]);
-          acc[kk][8] = fma(ind, tt, acc[kk][8]);
-        }
+      for (int kk = 0; kk < K; ++kk) {
+        const bool sel = valid && (k == kk);
+        nfree[kk] += (sel && !hit) ? 1u : 0u;
+        ncoll[kk] += (sel && hit) ? 1u : 0u;
+        const double ind = (sel && !hit) ? 1.0 : 0.0;
+        acc[kk][0] = fma(ind, x, acc[kk][0]);
+        acc[kk][1] = fma(ind, y, acc[kk][1]);
+        acc[kk][2] = fma(ind, t, acc[kk][2]);
+        acc[kk][3] = fma(ind, xx, acc[kk][3]);
+        acc[kk][4] = fma(ind, xy, acc[kk][4]);
+        acc[kk][5] = fma(ind, xt, acc[kk][5]);
+        acc[kk][6] = fma(ind, yy, acc[kk][6]);
+        acc[kk][7] = fma(ind, yt, acc[kk][7]);
+        acc[kk][8] = fma(ind, tt, acc[kk][8]);
       }
 #endif
     }
@@ -374,7 +332,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
       if (writer) { s_red[row][k * POCS_NMOM] = (double)nf; s_red[row][k * POCS_NMOM + 1] = (double)nc; }
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
-        const double v = row_sum(LDSACC ? s_acc[(k * 9 + j) * POCS_GMM_BLOCK + tid] : acc[LDSACC ? 0 : k][j]);
+        const double v = row_sum(acc[k][j]);
         if (writer) s_red[row][k * POCS_NMOM + 2 + j] = v;
       }
     }
@@ -384,7 +342,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   if (tid < NC) {
     double v = s_red[0][tid];
 #pragma unroll 8
-    for (int q = 1; q < POCS_GMM_BLOCK / 16; ++q) v += s_red[q][tid];
+    for (int q = 1; q < TB / 16; ++q) v += s_red[q][tid];
     store_wt(&a.partial[((size_t)r * gridDim.x + blockIdx.x) * NC + tid], v);
   }
   // hand-off: every storing wave drains its stores, the block meets, ONE lane takes a ticket;
@@ -403,7 +361,7 @@ __global__ __launch_bounds__(POCS_GMM_BLOCK) void k_gmm_step(pocs_gmm_launch a) 
   if (tid == 0 && blockIdx.y == 0 && blockIdx.x == 0 && a.waypoint == 5) for (int i = 0; i < 12; ++i) g_phase[32 + i] = ph[i];
 #endif
   if (s_last) {
-    constexpr int S = POCS_GMM_BLOCK / NC;
+    constexpr int S = TB / NC;
     const int q = tid / NC, c = tid - q * NC;
     double v = 0.0;
     if (q < S) {
@@ -563,8 +521,9 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_count(pocs_mc_launch a) {
 
 template <int K>
 hipError_t launch_gmm_k(int nblk, const pocs_gmm_launch& a, hipStream_t s) {
-  if (a.store) hipLaunchKernelGGL((k_gmm_step<K, true>), dim3(nblk, a.nruns), dim3(POCS_GMM_BLOCK), 0, s, a);
-  else         hipLaunchKernelGGL((k_gmm_step<K, false>), dim3(nblk, a.nruns), dim3(POCS_GMM_BLOCK), 0, s, a);
+  constexpr int TB = POCS_GMM_BLOCK_OF(K);
+  if (a.store) hipLaunchKernelGGL((k_gmm_step<K, true, TB>), dim3(nblk, a.nruns), dim3(TB), 0, s, a);
+  else         hipLaunchKernelGGL((k_gmm_step<K, false, TB>), dim3(nblk, a.nruns), dim3(TB), 0, s, a);
   return hipGetLastError();
 }
 
