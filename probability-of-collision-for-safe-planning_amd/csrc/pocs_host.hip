@@ -155,17 +155,31 @@ int grid_blocks(long long count, int block, int default_bpc) {
 // R runs shares the chip, so each run gets ~target/R blocks (fewer, fatter blocks: head, tail and
 // partial rows are amortised over more samples).  POCS_GRID_TARGET overrides the total for sweeps.
 int grid_for(long long count, int runs, int K) {
-  static int target = -1;
+  static int target = -1, forced_per = -1;
   if (target < 0) {
     const char* e = getenv("POCS_GRID_TARGET");
     target = e ? atoi(e) : 0;
     if (target < 0 || target > 8192) target = 0;
+    const char* f = getenv("POCS_BLOCKS_PER_RUN");            // sweeps
+    forced_per = f ? atoi(f) : 0;
+    if (forced_per < 0 || forced_per > 256) forced_per = 0;
   }
   const int one = grid_blocks(count, POCS_GMM_BLOCK_OF(K), 1);
   if (runs <= 1) return one;
-  int per = (target ? target : 256) / runs;      // floor: never more than one block per CU in all
-  if (per < 8) per = 8;
-  return per < one ? per : one;
+  if (forced_per) return forced_per < one ? forced_per : one;
+  if (target) { const int per = target / runs > 0 ? target / runs : 1; return per < one ? per : one; }
+  // A block occupies a CU by itself, so R * per blocks run in ceil(R * per / 256) rounds, each as
+  // long as one block: a run's samples / per, plus the block's fixed head and tail (~5 us against
+  // ~2.5 ms of one CU for 10^6 samples).  Take the cheapest `per`; ties go to fewer blocks.
+  const double t_run = 2560.0 * (double)count * 1e-6, t_fixed = 5.0;
+  int best = 1;
+  double best_cost = 1e300;
+  for (int per = 1; per <= one && per <= 256; ++per) {
+    const double rounds = (double)(((long long)runs * per + 255) / 256);
+    const double cost = rounds * (t_run / per + t_fixed);
+    if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = per; }
+  }
+  return best;
 }
 int grid_for_mc(long long count, int runs = 1) {                                      // MC kernels, per run
   const int one = grid_blocks(count, POCS_BLOCK, 3);
