@@ -26,7 +26,7 @@
 //   k_mc_count      P3        getCollisionProportion (:324-330): |{hits > 0}|.
 //
 // Bound: these are FP64-VALU / HBM streaming kernels, no contraction => no MFMA.  Mixture
-// parameters, the obstacle table and the 3 KB of log/sector tables are staged in LDS once per
+// parameters, the obstacle table and the 12 KB of log/sector tables are staged in LDS once per
 // block (all lanes read the same obstacle record => LDS broadcast; the per-lane component and
 // table lookups are 16-byte reads).  Reductions are DPP row sums followed by one LDS pass and a
 // per-block partial row; partials are combined in a fixed order so results are bitwise
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
 #if defined(POCS_TRACE_PHASES)
   if (threadIdx.x == 0 && blockIdx.y == 0) ph[11] = __builtin_readcyclecounter() - ph[10];
 #endif
-  // ---- tail: DPP row sums -> one LDS row per 16 lanes -> fixed-order sum over the 32 rows
+  // ---- tail: DPP row sums -> one LDS row per 16 lanes -> fixed-order sum over the TB/16 rows
   {
     const int row = tid >> 4;
     const bool writer = (tid & 15) == 0;
