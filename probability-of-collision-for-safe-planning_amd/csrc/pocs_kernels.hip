@@ -76,6 +76,13 @@ __device__ __forceinline__ void stage_tables(const pocs_tables* __restrict__ g, 
   for (int j = threadIdx.x; j < (int)(sizeof(pocs_tables) / sizeof(double)); j += blockDim.x) dst[j] = src[j];
 }
 
+// The MC kernels only evaluate the footprint heading: the 4 KB sector table is all they need.
+__device__ __forceinline__ void stage_sector_table(const pocs_tables* __restrict__ g, pocs_tables* s_tab) {
+  const double* src = &g->sc[0][0];
+  double* dst = &s_tab->sc[0][0];
+  for (int j = threadIdx.x; j < (int)(sizeof(g->sc) / sizeof(double)); j += blockDim.x) dst[j] = src[j];
+}
+
 // Stage the collision world into LDS.  s_obs must hold POCS_MAX_OBSTACLES*POCS_OBS_STRIDE doubles.
 __device__ __forceinline__ void stage_env(const pocs_env_dev* __restrict__ env, double* s_obs,
                                           pocs_footprint* s_fp, int* s_M) {
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_init(pocs_mc_launch a) {
   __shared__ int s_M;
   __shared__ pocs_tables s_tab;
   stage_env(a.env, s_obs, &s_fp, &s_M);
-  stage_tables(a.tables, &s_tab);
+  stage_sector_table(a.tables, &s_tab);
   __syncthreads();
   const mc_run_view v = mc_view(a);
   const pocs_footprint fp = s_fp;
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_step(pocs_mc_launch a) {
   __shared__ int s_M;
   __shared__ pocs_tables s_tab;
   stage_env(a.env, s_obs, &s_fp, &s_M);
-  stage_tables(a.tables, &s_tab);
+  stage_sector_table(a.tables, &s_tab);
   __syncthreads();
   const mc_run_view v = mc_view(a);
   const pocs_footprint fp = s_fp;
@@ -473,7 +480,7 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_fused(pocs_mc_launch a) {
   __shared__ int s_M;
   __shared__ pocs_tables s_tab;
   stage_env(a.env, s_obs, &s_fp, &s_M);
-  stage_tables(a.tables, &s_tab);
+  stage_sector_table(a.tables, &s_tab);
   __syncthreads();
   const mc_run_view v = mc_view(a);
   const pocs_footprint fp = s_fp;
