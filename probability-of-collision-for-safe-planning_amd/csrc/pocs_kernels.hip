@@ -260,7 +260,14 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
       zz[0][0] = (double)A.x * 0x1p-32; zz[0][1] = (double)A.y * 0x1p-32; zz[0][2] = (double)A.z * 0x1p-32; spare[0] = B.z;
       zz[1][0] = (double)A.w * 0x1p-32; zz[1][1] = (double)B.x * 0x1p-32; zz[1][2] = (double)B.y * 0x1p-32; spare[1] = B.w; }
 #else
-    pocs_normal3_pair(seed, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, &s_tab, zz[0], zz[1], &spare[0], &spare[1]);
+    // The seed is made opaque once per iteration: otherwise the compiler hoists all 20 Philox round
+    // keys (seed + r * Weyl constants) out of the loop and pins 20 SGPRs of a register file that is
+    // already spilling; recomputing them costs 2 scalar adds per round.
+    uint64_t seed_it = seed;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(seed_it));
+#endif
+    pocs_normal3_pair(seed_it, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, &s_tab, zz[0], zz[1], &spare[0], &spare[1]);
 #endif
     const long long i0 = 2 * lp;
     const bool two = (i0 + 1) < a.count;          // false only for the last sample of an odd shard
