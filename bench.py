@@ -115,6 +115,11 @@ def main():
     # runs and the rest of b_lo runs.
     maxb = args.batch if args.batch > 0 else (64 if path == "gmm" else 8)
     ncalls = (args.steps + maxb - 1) // maxb
+    if sharded and path == "gmm" and args.steps >= 2:
+        # N > 1: an even number of calls, so that two engines are always in flight and one engine's
+        # all-reduce is covered by the other's kernel
+        ncalls = max(2, ncalls + (ncalls & 1))
+        ncalls = min(ncalls, args.steps - (args.steps & 1)) or 2
     b_lo, n_hi = divmod(args.steps, ncalls)
     b_hi = b_lo + 1 if n_hi else b_lo
     batch = b_hi
