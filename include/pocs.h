@@ -72,6 +72,11 @@ int pocs_send_command(pocs_ctx* ctx, const char* line, char* out, size_t cap);
 #define POCS_OPT_MC_FUSED 2        /* 0 (default): one launch per waypoint, particles streamed through HBM (56 B/eval); 1: whole roll-out in registers */
 #define POCS_OPT_USE_GRAPH 3       /* 1 (default): the per-run launch sequence is replayed from a hipGraph */
 #define POCS_OPT_PROFILE 4         /* 1: bracket the hot kernel with hipEvents (see pocs_get_kernel_time) */
+#define POCS_OPT_RUN_AHEAD 5       /* R > 1 (default 1 = off): with one run per call (batch 1), a run* call evaluates the NEXT R
+                                      runs of the context in one launch and the following R-1 calls are served from it -- the
+                                      reference driver's one-command-per-run loop (MCSimulation.py:238-256) at batch throughput.
+                                      Same runs, same seeds, same results and getters as one launch per run; any setter ends the
+                                      serving and the run counter resumes after the last run handed out.  Text: setRunAhead R */
 int pocs_set_option(pocs_ctx* ctx, int option, long long value);
 
 /* ---- batches of independent runs (ours) --------------------------------------------------

@@ -4,6 +4,7 @@
 //   g++ -shared -fPIC mcsimplugin_pocs.cpp $(openrave-config --cflags --libs-core) -I../include -lpocs
 #include <openrave/plugin.h>
 #include <boost/bind.hpp>
+#include <cstdlib>
 
 #include "../probability-of-collision-for-safe-planning_amd/csrc/mcmodule.hpp"
 
@@ -15,9 +16,13 @@ class MCModule : public ModuleBase {
     static const char* const names[] = {"MyCommand", "ArmaCommand", "setAlphas", "setQ", "setNumLandmarks",
         "setLandmarks", "setNumParticles", "setInitialCovariance", "setPathLength", "setTrajectory",
         "setOdometry", "runSimulation", "setNumGaussians", "runGMMEstimation", "setNumGMMSamples",
-        "setSeed", "setFootprint", "addObstacle", "clearObstacles"};
+        "setSeed", "setFootprint", "addObstacle", "clearObstacles", "setBatch", "setRunAhead"};
     for (const char* n : names)
       RegisterCommand(n, boost::bind(&MCModule::Forward, this, std::string(n), _1, _2), "see include/pocs.h");
+    // The reference driver issues one run* command per run, 200 in a row (MCSimulation.py:238-256):
+    // evaluate them 16 at a time behind that interface (POCS_RUN_AHEAD overrides; 1 = off).
+    const char* ra = getenv("POCS_RUN_AHEAD");
+    impl_.SendCommand(std::string("setRunAhead ") + (ra ? ra : "16"));
   }
   bool Forward(const std::string& name, std::ostream& sout, std::istream& sinput) {
     std::stringstream line;

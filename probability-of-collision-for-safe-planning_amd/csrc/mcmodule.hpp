@@ -54,6 +54,8 @@ class MCModule {
         {"setFootprint", "(new) dx dy half_x half_y of the robot footprint"},
         {"addObstacle", "(new) cx cy half_x half_y yaw_rad of a static box"},
         {"clearObstacles", "(new) forget all obstacles"},
+        {"setBatch", "(new) r independent runs advanced in lockstep per run* command"},
+        {"setRunAhead", "(new) r: one run per command, the next r runs evaluated in one launch"},
     };
     for (const auto& c : kCommands) {
       const std::string name = c[0];

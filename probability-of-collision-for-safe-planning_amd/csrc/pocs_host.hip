@@ -60,6 +60,17 @@ struct pocs_ctx {
   long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0;
   unsigned long long epoch = 0;          // bumped by every setter; part of the graph cache key
   int batch = 1;                         // independent GMM estimations advanced in lockstep per call
+  // run-ahead (POCS_OPT_RUN_AHEAD): with batch == 1 a run* call evaluates the next `run_ahead` runs
+  // of the context in one launch and the following calls are served from it; `view` is the run of
+  // the last launch the getters expose.
+  int run_ahead = 1;
+  int view = 0;
+  int ra_have = 0;                       // runs of the last launch that may still be served (0: none)
+  int ra_kind = 0;                       // 1 GMM, 2 MC
+  bool ra_internal = false;              // the last launch was an internal run-ahead batch
+  uint64_t batch_base = 0;               // run_index of run 0 of the last launch
+  int batch_R = 1;                       // runs in the last launch
+  std::vector<double> batch_moments;     // [W][R][K*11] of the last GMM launch
 
   // host image (headers | chains | initial mixtures) of the NEXT batch, computed while the GPU
   // works on the current one
@@ -337,6 +348,17 @@ uint64_t effective_seed(const pocs_ctx* c, uint64_t ahead = 0) {
   return c->seed + 0x9E3779B97F4A7C15ull * (c->run_index + ahead);
 }
 
+uint64_t seed_of_run(const pocs_ctx* c, uint64_t run) { return c->seed + 0x9E3779B97F4A7C15ull * run; }
+
+// Run-ahead bookkeeping.  A setter (or any other launch) ends the serving of cached runs: the
+// context's run counter goes back to just after the last run that was handed out, so the sequence
+// of seeds the caller sees is the one it would have seen one run per launch.
+void ra_drop(pocs_ctx* c) {
+  if (c->ra_have > 0) c->run_index = c->batch_base + (uint64_t)c->view + 1;
+  c->ra_have = 0;
+}
+void touch(pocs_ctx* c) { ra_drop(c); c->epoch++; }
+
 double* moments_dev(pocs_ctx* c) { return c->ext_moments ? c->ext_moments : (double*)c->d_moments.p; }
 
 int prof_begin(pocs_ctx* c, size_t launches) {
@@ -458,6 +480,9 @@ int stage_and_upload_runs(pocs_ctx* c) {
     build_run_image(c, 0, pin);
   }
   a.valid = false;
+  c->batch_base = c->run_index;
+  c->batch_R = R;
+  c->view = 0;
   c->run_index += (uint64_t)R;
   HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, pin, (size_t)R * sizeof(pocs_run_header), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_chain.p, pin + pl.chain, (size_t)R * steps * POCS_CHAIN_STRIDE * sizeof(double),
@@ -536,11 +561,26 @@ int enqueue_gmm_all(pocs_ctx* c, long long first, long long count, bool prof) {
 }
 
 // F1 (MCSimulator.h:848-856): p_w = colliding / numGMMSamples (:633-641), result = 1 - prod(1 - p_w)
+// The getters' view of the last GMM launch: per-waypoint probabilities and moments of run v.
+void gmm_select_view(pocs_ctx* c, int v) {
+  const int W = c->W, K = c->K, R = c->batch_R;
+  c->view = v;
+  c->probs.assign(W, 0.0);
+  c->last_moments.assign((size_t)W * K * POCS_NMOM, 0.0);
+  for (int w = 0; w < W; ++w) {
+    const double* m = &c->batch_moments[((size_t)w * R + v) * K * POCS_NMOM];
+    double coll = 0.0;
+    for (int k = 0; k < K; ++k) coll += m[(size_t)k * POCS_NMOM + 1];
+    c->probs[w] = coll / (1.0 * (double)c->num_gmm);
+    memcpy(&c->last_moments[(size_t)w * K * POCS_NMOM], m, (size_t)K * POCS_NMOM * sizeof(double));
+  }
+}
+
 void gmm_combine(pocs_ctx* c, const double* moments, double* probability) {
   const int W = c->W, K = c->K, R = c->batch;          // moments: [W][R][K*11]
-  c->probs.assign(W, 0.0);
+  c->batch_R = R;
+  c->batch_moments.assign(moments, moments + (size_t)W * R * K * POCS_NMOM);
   c->batch_probs.assign(R, 0.0);
-  c->last_moments.assign((size_t)W * K * POCS_NMOM, 0.0);
   for (int r = 0; r < R; ++r) {
     double prod = 1.0;
     for (int w = 0; w < W; ++w) {
@@ -549,13 +589,10 @@ void gmm_combine(pocs_ctx* c, const double* moments, double* probability) {
       for (int k = 0; k < K; ++k) coll += m[(size_t)k * POCS_NMOM + 1];
       const double p = coll / (1.0 * (double)c->num_gmm);
       prod *= (1.0 - p);
-      if (r == 0) {
-        c->probs[w] = p;
-        memcpy(&c->last_moments[(size_t)w * K * POCS_NMOM], m, (size_t)K * POCS_NMOM * sizeof(double));
-      }
     }
     c->batch_probs[r] = 1.0 - prod;
   }
+  gmm_select_view(c, 0);
   *probability = c->batch_probs[0];
 }
 
@@ -750,6 +787,7 @@ const char* kHelp =
     "addObstacle      cx cy half_x half_y yaw_rad (new)\n"
     "clearObstacles   (new)\n"
     "setBatch         r: independent GMM estimations advanced in lockstep per runGMMEstimation (new)\n"
+    "setRunAhead      r: with one run per command, evaluate the next r runs in one launch and serve the following commands from it (new)\n"
     "help             this text\n";
 
 }  // namespace
@@ -801,7 +839,7 @@ void pocs_destroy(pocs_ctx* c) {
 const char* pocs_last_error(const pocs_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int pocs_set_footprint(pocs_ctx* c, double dx, double dy, double hx, double hy) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (!(hx > 0) || !(hy > 0)) return fail(c, POCS_E_ARG, "footprint half extents must be > 0");
   c->fp.dx = dx; c->fp.dy = dy; c->fp.hx = hx; c->fp.hy = hy;
@@ -810,7 +848,7 @@ int pocs_set_footprint(pocs_ctx* c, double dx, double dy, double hx, double hy) 
 }
 
 int pocs_set_obstacles(pocs_ctx* c, const double* boxes, int M) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (M < 0 || M > POCS_MAX_OBSTACLES || (M > 0 && !boxes))
     return fail(c, POCS_E_ARG, "obstacle count %d outside 0..%d", M, POCS_MAX_OBSTACLES);
@@ -823,7 +861,7 @@ int pocs_set_obstacles(pocs_ctx* c, const double* boxes, int M) {
 }
 
 int pocs_set_alphas(pocs_ctx* c, const double* a, int n) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (n < 1 || n > 4 || !a) return fail(c, POCS_E_ARG, "setAlphas takes 1..4 values (got %d)", n);
   for (int i = 0; i < n; ++i) c->alphas[i] = a[i];
@@ -832,7 +870,7 @@ int pocs_set_alphas(pocs_ctx* c, const double* a, int n) {
 }
 
 int pocs_set_q(pocs_ctx* c, double q) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (!(q >= 0)) return fail(c, POCS_E_ARG, "Q must be >= 0");
   c->sensor.Q = q; c->have_q = true; c->sensor_dirty = true;
@@ -840,7 +878,7 @@ int pocs_set_q(pocs_ctx* c, double q) {
 }
 
 int pocs_set_num_landmarks(pocs_ctx* c, int n) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (n < 0 || n > POCS_MAX_LANDMARKS) return fail(c, POCS_E_ARG, "numLandmarks %d outside 0..%d", n, POCS_MAX_LANDMARKS);
   c->num_landmarks = n; c->have_landmarks = false;
@@ -848,7 +886,7 @@ int pocs_set_num_landmarks(pocs_ctx* c, int n) {
 }
 
 int pocs_set_landmarks(pocs_ctx* c, const double* xy, int n) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (c->num_landmarks < 0) return fail(c, POCS_E_ORDER, "setLandmarks before setNumLandmarks");
   if (n != c->num_landmarks || (n > 0 && !xy)) return fail(c, POCS_E_ARG, "setLandmarks needs 2*%d values", c->num_landmarks);
@@ -859,7 +897,7 @@ int pocs_set_landmarks(pocs_ctx* c, const double* xy, int n) {
 }
 
 int pocs_set_num_particles(pocs_ctx* c, long long n) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (n < 1) return fail(c, POCS_E_ARG, "numParticles must be >= 1");
   c->num_particles = n;
@@ -867,7 +905,7 @@ int pocs_set_num_particles(pocs_ctx* c, long long n) {
 }
 
 int pocs_set_initial_covariance(pocs_ctx* c, const double* m9) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c || !m9) return POCS_E_ARG;
   memcpy(c->cov0, m9, 9 * sizeof(double));
   c->have_cov0 = true;
@@ -875,7 +913,7 @@ int pocs_set_initial_covariance(pocs_ctx* c, const double* m9) {
 }
 
 int pocs_set_path_length(pocs_ctx* c, int W) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (W < 1) return fail(c, POCS_E_ARG, "pathLength must be >= 1");
   if (W != c->W) { c->have_traj = false; c->have_odom = false; }
@@ -884,7 +922,7 @@ int pocs_set_path_length(pocs_ctx* c, int W) {
 }
 
 int pocs_set_trajectory(pocs_ctx* c, const double* v, int W) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (c->W < 1) return fail(c, POCS_E_ORDER, "setTrajectory before setPathLength");
   if (W != c->W || !v) return fail(c, POCS_E_ARG, "setTrajectory needs 3*%d values", c->W);
@@ -894,7 +932,7 @@ int pocs_set_trajectory(pocs_ctx* c, const double* v, int W) {
 }
 
 int pocs_set_odometry(pocs_ctx* c, const double* v, int Wm1) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (c->W < 1) return fail(c, POCS_E_ORDER, "setOdometry before setPathLength");
   if (Wm1 != c->W - 1 || (Wm1 > 0 && !v)) return fail(c, POCS_E_ARG, "setOdometry needs 3*%d values", c->W - 1);
@@ -904,7 +942,7 @@ int pocs_set_odometry(pocs_ctx* c, const double* v, int Wm1) {
 }
 
 int pocs_set_num_gaussians(pocs_ctx* c, int K) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (K < 1 || K > POCS_MAX_GAUSSIANS) return fail(c, POCS_E_ARG, "numGaussians %d outside 1..%d", K, POCS_MAX_GAUSSIANS);
   c->K = K;
@@ -912,7 +950,7 @@ int pocs_set_num_gaussians(pocs_ctx* c, int K) {
 }
 
 int pocs_set_num_gmm_samples(pocs_ctx* c, long long n) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (n < 1) return fail(c, POCS_E_ARG, "numGMMSamples must be >= 1");
   c->num_gmm = n;
@@ -920,20 +958,24 @@ int pocs_set_num_gmm_samples(pocs_ctx* c, long long n) {
 }
 
 int pocs_set_seed(pocs_ctx* c, uint64_t seed) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   c->seed = seed; c->run_index = 0;
   return POCS_OK;
 }
 
 int pocs_set_option(pocs_ctx* c, int option, long long value) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   switch (option) {
     case POCS_OPT_STORE_SAMPLES: c->opt_store = value ? 1 : 0; break;
     case POCS_OPT_MC_FUSED: c->opt_fused = value ? 1 : 0; break;
     case POCS_OPT_USE_GRAPH: c->opt_graph = value ? 1 : 0; break;
     case POCS_OPT_PROFILE: c->opt_profile = value ? 1 : 0; break;
+    case POCS_OPT_RUN_AHEAD:
+      if (value < 1 || value > 256) return fail(c, POCS_E_ARG, "run-ahead %lld outside 1..256", value);
+      c->run_ahead = (int)value;
+      break;
     default: return fail(c, POCS_E_ARG, "unknown option %d", option);
   }
   return POCS_OK;
@@ -941,7 +983,7 @@ int pocs_set_option(pocs_ctx* c, int option, long long value) {
 
 int pocs_set_batch(pocs_ctx* c, int runs) {
   if (!c) return POCS_E_ARG;
-  c->epoch++;
+  touch(c);
   if (runs < 1 || runs > 256) return fail(c, POCS_E_ARG, "batch %d outside 1..256", runs);
   if (c->gmm_open) return fail(c, POCS_E_ORDER, "pocs_set_batch inside a begin/end sequence");
   c->batch = runs;
@@ -950,13 +992,18 @@ int pocs_set_batch(pocs_ctx* c, int runs) {
 
 int pocs_get_batch_probabilities(pocs_ctx* c, double* out, int cap) {
   if (!c || !out) return POCS_E_ARG;
+  if (c->ra_internal) {                       // the caller asked for one run at a time
+    if (cap < 1 || c->batch_probs.empty()) return fail(c, POCS_E_BUFFER, "need 1 double");
+    out[0] = c->batch_probs[(size_t)c->view];
+    return 1;
+  }
   if ((int)c->batch_probs.size() > cap) return fail(c, POCS_E_BUFFER, "need %zu doubles", c->batch_probs.size());
   memcpy(out, c->batch_probs.data(), c->batch_probs.size() * sizeof(double));
   return (int)c->batch_probs.size();
 }
 
 int pocs_set_shard(pocs_ctx* c, long long first, long long count) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   if (first == -1 && count == -1) { c->shard_first = -1; c->shard_count = -1; return POCS_OK; }   // whole range
   if (first < 0 || count < 0) return fail(c, POCS_E_ARG, "negative shard");
@@ -965,7 +1012,7 @@ int pocs_set_shard(pocs_ctx* c, long long first, long long count) {
 }
 
 int pocs_set_stream(pocs_ctx* c, void* s) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   c->stream = s ? (hipStream_t)s : c->own_stream;
   drop_graphs(c);
@@ -973,28 +1020,64 @@ int pocs_set_stream(pocs_ctx* c, void* s) {
 }
 
 int pocs_gmm_bind_moments(pocs_ctx* c, void* dptr, long long len) {
-  if (c) c->epoch++;
+  if (c) touch(c);
   if (!c) return POCS_E_ARG;
   c->ext_moments = (double*)dptr; c->ext_moments_len = dptr ? len : 0;
   drop_graphs(c);
   return POCS_OK;
 }
 
+// run* with run-ahead: serve the next cached run, or evaluate the next `run_ahead` runs at once.
+static bool ra_can_serve(const pocs_ctx* c, int kind) {
+  return c->ra_have > 0 && c->ra_kind == kind && c->batch == 1 && c->view + 1 < c->ra_have;
+}
+static bool ra_wanted(const pocs_ctx* c) {
+  return c->run_ahead > 1 && c->batch == 1 && c->shard_first < 0 && !c->opt_profile && !c->ext_moments && !c->gmm_open;
+}
+static void mc_fill_probs(pocs_ctx* c) {
+  // getCollisionProportion, MCSimulator.h:324-330 (of the particles this context evaluated)
+  const double den = (double)(c->last_mc_count > 0 ? c->last_mc_count : 1);
+  c->batch_probs.assign(c->mc_counts.size(), 0.0);
+  for (size_t r = 0; r < c->mc_counts.size(); ++r) c->batch_probs[r] = (double)c->mc_counts[r] / den;
+}
+
 int pocs_run_gmm_estimation(pocs_ctx* c, double* probability) {
   if (!c) return POCS_E_ARG;
+  if (!probability) return fail(c, POCS_E_ARG, "null output");
   HIPCHK(c, hipSetDevice(c->device));
-  return run_gmm_full(c, probability);
+  if (ra_can_serve(c, 1)) {
+    gmm_select_view(c, c->view + 1);
+    *probability = c->batch_probs[(size_t)c->view];
+    return POCS_OK;
+  }
+  ra_drop(c);
+  c->ra_internal = false;
+  if (!ra_wanted(c)) return run_gmm_full(c, probability);
+  c->batch = c->run_ahead;
+  const int rc = run_gmm_full(c, probability);
+  c->batch = 1;
+  if (rc == POCS_OK) { c->ra_have = c->run_ahead; c->ra_kind = 1; c->ra_internal = true; }
+  return rc;
 }
 
 int pocs_run_simulation(pocs_ctx* c, double* probability) {
   if (!c) return POCS_E_ARG;
   if (!probability) return fail(c, POCS_E_ARG, "null output");
   HIPCHK(c, hipSetDevice(c->device));
-  if (int r = run_mc_local(c)) return r;
-  // getCollisionProportion, MCSimulator.h:324-330 (of the particles this context evaluated)
-  const double den = (double)(c->last_mc_count > 0 ? c->last_mc_count : 1);
-  c->batch_probs.assign(c->mc_counts.size(), 0.0);
-  for (size_t r = 0; r < c->mc_counts.size(); ++r) c->batch_probs[r] = (double)c->mc_counts[r] / den;
+  if (ra_can_serve(c, 2)) {
+    c->view += 1;
+    *probability = c->batch_probs[(size_t)c->view];
+    return POCS_OK;
+  }
+  ra_drop(c);
+  c->ra_internal = false;
+  const bool ra = ra_wanted(c);
+  if (ra) c->batch = c->run_ahead;
+  const int rc = run_mc_local(c);
+  c->batch = ra ? 1 : c->batch;
+  if (rc) return rc;
+  mc_fill_probs(c);
+  if (ra) { c->ra_have = c->run_ahead; c->ra_kind = 2; c->ra_internal = true; }
   *probability = c->batch_probs[0];
   return POCS_OK;
 }
@@ -1003,6 +1086,8 @@ int pocs_mc_run_local(pocs_ctx* c, unsigned long long* collided) {
   if (!c) return POCS_E_ARG;
   if (!collided) return fail(c, POCS_E_ARG, "null output");
   HIPCHK(c, hipSetDevice(c->device));
+  ra_drop(c);
+  c->ra_internal = false;
   if (int r = run_mc_local(c)) return r;
   *collided = c->mc_counts[0];
   return POCS_OK;
@@ -1010,6 +1095,11 @@ int pocs_mc_run_local(pocs_ctx* c, unsigned long long* collided) {
 
 int pocs_mc_get_batch_counts(pocs_ctx* c, unsigned long long* out, int cap) {
   if (!c || !out) return POCS_E_ARG;
+  if (c->ra_internal) {                       // the caller asked for one run at a time
+    if (cap < 1 || c->mc_counts.empty()) return fail(c, POCS_E_BUFFER, "need 1 counter");
+    out[0] = c->mc_counts[(size_t)c->view];
+    return 1;
+  }
   if ((int)c->mc_counts.size() > cap) return fail(c, POCS_E_BUFFER, "need %zu counters", c->mc_counts.size());
   memcpy(out, c->mc_counts.data(), c->mc_counts.size() * sizeof(unsigned long long));
   return (int)c->mc_counts.size();
@@ -1018,6 +1108,8 @@ int pocs_mc_get_batch_counts(pocs_ctx* c, unsigned long long* out, int cap) {
 int pocs_gmm_begin(pocs_ctx* c) {
   if (!c) return POCS_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  ra_drop(c);
+  c->ra_internal = false;
   if (int r = gmm_prepare(c)) return r;
   if (int r = gmm_upload_run(c)) return r;
   if (int r = prof_begin(c, (size_t)c->W)) return r;
@@ -1088,7 +1180,8 @@ int pocs_get_gmm_state(pocs_ctx* c, int w, double* means3, double* covs9, double
   HIPCHK(c, hipSetDevice(c->device));
   std::vector<double> s((size_t)c->K * POCS_STATE_STRIDE);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(s.data(), (double*)c->d_state.p + (size_t)w * s.size(), s.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const double* run_state = (double*)c->d_state.p + (size_t)c->view * c->W * s.size();    // [run][W][K*16]
+  HIPCHK(c, hipMemcpy(s.data(), run_state + (size_t)w * s.size(), s.size() * sizeof(double), hipMemcpyDeviceToHost));
   for (int k = 0; k < c->K; ++k) {
     if (means3) memcpy(means3 + 3 * k, &s[(size_t)k * POCS_STATE_STRIDE], 3 * sizeof(double));
     if (covs9) memcpy(covs9 + 9 * k, &s[(size_t)k * POCS_STATE_STRIDE + 3], 9 * sizeof(double));
@@ -1103,6 +1196,7 @@ int pocs_get_host_chain(pocs_ctx* c, double* applied3, double* noisy3, double* z
   const int steps = c->W - 1, L = c->sensor.L;
   if (steps < 0 || c->h_chain.size() < (size_t)(steps > 0 ? steps : 1) * POCS_CHAIN_STRIDE)
     return fail(c, POCS_E_STATE, "no run yet");
+  if (c->view != 0) compute_chain(c, seed_of_run(c, c->batch_base + (uint64_t)c->view));   // h_chain holds run 0's
   for (int i = 0; i < steps; ++i) {
     const double* rec = &c->h_chain[(size_t)i * POCS_CHAIN_STRIDE];
     if (applied3) memcpy(applied3 + 3 * i, rec, 3 * sizeof(double));
@@ -1115,11 +1209,11 @@ int pocs_get_host_chain(pocs_ctx* c, double* applied3, double* noisy3, double* z
 }
 
 static long long copy_soa_as_aos(pocs_ctx* c, const DevBuf& bx, const DevBuf& by, const DevBuf& bt,
-                                 long long n, double* aos) {
+                                 size_t first, long long n, double* aos) {
   std::vector<double> tmp((size_t)n);
   const DevBuf* src[3] = {&bx, &by, &bt};
   for (int j = 0; j < 3; ++j) {
-    if (hipMemcpy(tmp.data(), src[j]->p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(tmp.data(), (const double*)src[j]->p + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     for (long long i = 0; i < n; ++i) aos[3 * i + j] = tmp[(size_t)i];
   }
   (void)c;
@@ -1133,8 +1227,9 @@ long long pocs_copy_gmm_samples(pocs_ctx* c, double* aos, int16_t* flags, long l
   if (cap < n) return fail(c, POCS_E_BUFFER, "need room for %lld samples", n);
   if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
     return fail(c, POCS_E_DEVICE, "sync failed");
-  if (aos && copy_soa_as_aos(c, c->d_sx, c->d_sy, c->d_st, n, aos) < 0) return fail(c, POCS_E_DEVICE, "copy failed");
-  if (flags && hipMemcpy(flags, c->d_flags.p, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost) != hipSuccess)
+  const size_t off = (size_t)c->view * (size_t)sample_stride_of(n);          // this run's slice
+  if (aos && copy_soa_as_aos(c, c->d_sx, c->d_sy, c->d_st, off, n, aos) < 0) return fail(c, POCS_E_DEVICE, "copy failed");
+  if (flags && hipMemcpy(flags, (const int16_t*)c->d_flags.p + off, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost) != hipSuccess)
     return fail(c, POCS_E_DEVICE, "copy failed");
   return n;
 }
@@ -1146,8 +1241,9 @@ long long pocs_copy_particles(pocs_ctx* c, double* aos, uint32_t* hits, long lon
   if (cap < n) return fail(c, POCS_E_BUFFER, "need room for %lld particles", n);
   if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
     return fail(c, POCS_E_DEVICE, "sync failed");
-  if (aos && copy_soa_as_aos(c, c->d_px, c->d_py, c->d_pt, n, aos) < 0) return fail(c, POCS_E_DEVICE, "copy failed");
-  if (hits && hipMemcpy(hits, c->d_hits.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+  const size_t off = (size_t)c->view * (size_t)sample_stride_of(n);          // this run's slice
+  if (aos && copy_soa_as_aos(c, c->d_px, c->d_py, c->d_pt, off, n, aos) < 0) return fail(c, POCS_E_DEVICE, "copy failed");
+  if (hits && hipMemcpy(hits, (const uint32_t*)c->d_hits.p + off, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
     return fail(c, POCS_E_DEVICE, "copy failed");
   return n;
 }
@@ -1257,6 +1353,7 @@ int pocs_send_command(pocs_ctx* c, const char* line, char* out, size_t cap) {
   }
   if (name == "clearObstacles") return pocs_set_obstacles(c, nullptr, 0);
   if (name == "setBatch") { if (int r = one_int(&n)) return r; return pocs_set_batch(c, (int)n); }
+  if (name == "setRunAhead") { if (int r = one_int(&n)) return r; return pocs_set_option(c, POCS_OPT_RUN_AHEAD, n); }
   if (name == "runSimulation" || name == "runGMMEstimation") {                 // :75-81, :66-72
     double p = 0.0;
     const int r = (name == "runSimulation") ? pocs_run_simulation(c, &p) : pocs_run_gmm_estimation(c, &p);

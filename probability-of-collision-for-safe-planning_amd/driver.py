@@ -83,12 +83,14 @@ def summary(props, times):
 
 
 def run_experiment(simoption, num_runs=200, num_particles=10000, num_gaussians=3, seed=1, device=0,
-                   plan=None, env=None, envfile=None, params=None, out_dir=".", stamp=None, batch=1):
+                   plan=None, env=None, envfile=None, params=None, out_dir=".", stamp=None, batch=1, run_ahead=1):
     """MCSimulation.py:221-269.  Returns dict(times, proportions, journal, report, summary).
 
     batch=1 issues one run per command like the reference.  batch=R (ours) advances R of the
     independent runs per command in lockstep on the GPU (pocs_set_batch): same runs, same seeds,
-    same journal and report; a run's simTime is then its call's wall time / R."""
+    same journal and report; a run's simTime is then its call's wall time / R.
+    run_ahead=R (ours) keeps one command per run but lets the library evaluate the next R runs in
+    one launch (setRunAhead): same runs again; the first command of a group carries the group's time."""
     if simoption not in ("MC", "GMM"):
         raise ValueError('simoption must be "MC" or "GMM"')              # MCSimulation.py:108-111
     plan = plan or planio.load_plan()
@@ -104,6 +106,8 @@ def run_experiment(simoption, num_runs=200, num_particles=10000, num_gaussians=3
     with Context(device) as mod, open(journal, "w") as f2:
         push_configuration(mod, plan, env, params, num_particles, simoption, num_gaussians)
         mod.SendCommand("setSeed " + str(int(seed)))
+        if int(run_ahead) > 1:
+            mod.SendCommand("setRunAhead " + str(int(run_ahead)))
         command = "runSimulation" if simoption == "MC" else "runGMMEstimation"
         batch = max(1, int(batch))
         i = 0
@@ -137,12 +141,13 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--batch", type=int, default=1, help="runs advanced in lockstep per command (1 = like the reference)")
+    ap.add_argument("--run-ahead", type=int, default=1, help="one command per run, the next R runs evaluated in one launch")
     ap.add_argument("--plan", default=None)
     ap.add_argument("--env", default=None)
     ap.add_argument("--out", default=".")
     a = ap.parse_args(argv)
     r = run_experiment(a.simoption, a.runs, a.particles, a.gaussians, a.seed, a.device,
-                       plan=planio.load_plan(a.plan) if a.plan else None, envfile=a.env, out_dir=a.out, batch=a.batch)
+                       plan=planio.load_plan(a.plan) if a.plan else None, envfile=a.env, out_dir=a.out, batch=a.batch, run_ahead=a.run_ahead)
     s = r["summary"]
     print("Average Prob Collision: %.6f  (sd %.6f, range %.4f-%.4f), Average Sim Time: %.6f s"
           % (s["mean"], s["std"], s["min"], s["max"], s["mean_time"]))

@@ -50,6 +50,15 @@ int main(int argc, char** argv) {
     std::printf("GMM %s\n", mod.SendCommand("runGMMEstimation").c_str());
     mod.SendCommand(std::string("setSeed ") + argv[5]);
     std::printf("MC %s\n", mod.SendCommand("runSimulation").c_str());
+    // one run per command with and without run-ahead: the same six MC results
+    std::string plain, ahead;
+    mod.SendCommand(std::string("setSeed ") + argv[5]);
+    for (int i = 0; i < 6; ++i) plain += mod.SendCommand("runSimulation") + " ";
+    mod.SendCommand("setRunAhead 4");
+    mod.SendCommand(std::string("setSeed ") + argv[5]);
+    for (int i = 0; i < 6; ++i) ahead += mod.SendCommand("runSimulation") + " ";
+    mod.SendCommand("setRunAhead 1");
+    std::printf("AHEAD %d\n", plain == ahead ? 1 : 0);
     std::istringstream bad("setLandmarks 1 2 3"); std::ostringstream sink;
     std::printf("BADCMD %d\n", mod.SendCommand(sink, bad) ? 1 : 0);
     const std::string helptext = help.str();

@@ -56,3 +56,12 @@ def test_driver_batched_runs_are_the_same_runs(driver, tmp_path, mode):
     j = bat["journal"].read_text().splitlines()
     assert len(j) == 15 and j[12] == "Simulation: 4"
     assert "NumSimulations: 5" in bat["report"].read_text()
+
+
+@pytest.mark.gpu
+def test_driver_run_ahead_is_transparent(driver, tmp_path):
+    """run_ahead=R: still one command per run (the reference's loop), same proportions."""
+    one = driver.run_experiment("MC", num_runs=7, num_particles=2500, seed=5, out_dir=tmp_path / "one")
+    ra = driver.run_experiment("MC", num_runs=7, num_particles=2500, seed=5, out_dir=tmp_path / "ra", run_ahead=3)
+    assert one["proportions"] == ra["proportions"]
+    assert len(ra["journal"].read_text().splitlines()) == 21

@@ -481,3 +481,64 @@ def test_full_size_properties(ctx, pocs, plan, env):
     ctx.set_seed(SEED)
     assert ctx.run_gmm_estimation() == p1                       # bitwise reproducible
     assert 0.0 < p1 <= 1.0
+
+
+def _snapshot(ctx, K, N, mc):
+    """Everything a caller can read after a run."""
+    if mc:
+        xyz, hits = ctx.particles(N)
+        return dict(xyz=xyz.copy(), hits=hits.copy(), counts=list(ctx.mc_batch_counts()),
+                    bp=list(ctx.batch_probabilities()))
+    xyz, flags = ctx.gmm_samples(N)
+    hc = ctx.host_chain(8)
+    return dict(probs=ctx.waypoint_probabilities().copy(), m7=ctx.moments(7, K).copy(), m55=ctx.moments(55, K).copy(),
+                st=ctx.gmm_state_raw(30, K).copy(), xyz=xyz.copy(), flags=flags.copy(), app=hc["applied"].copy(),
+                z=hc["z"].copy(), mu=hc["mu"].copy(), bp=list(ctx.batch_probabilities()))
+
+
+def _same(a, b):
+    return a.keys() == b.keys() and all(np.array_equal(np.asarray(a[k]), np.asarray(b[k])) for k in a)
+
+
+@pytest.mark.parametrize("mc", [False, True])
+def test_run_ahead_serves_the_same_runs(pocs, plan, env, mc):
+    """POCS_OPT_RUN_AHEAD: one run per call, the next R runs evaluated in one launch.  The sequence
+    of results AND of everything the getters expose must be what one launch per run gives --
+    across the refill (R = 4, 11 calls), a setter in the middle of a served group (the run counter
+    resumes after the last run handed out) and a seed rewind."""
+    K, N = 3, 4000
+
+    def sequence(run_ahead):
+        out = []
+        with pocs.Context(0) as c:
+            c.configure(plan, env, K=K, N=N, seed=41)
+            c.set_num_particles(N)
+            if run_ahead > 1:
+                c.send_command("setRunAhead %d" % run_ahead)
+            run = c.run_simulation if mc else c.run_gmm_estimation
+            for i in range(11):
+                out.append((run(), _snapshot(c, K, N, mc)))
+            c.set_q(pocs.DEFAULTS["Q"])                      # a setter after run 2 of a group of 4
+            for i in range(3):
+                out.append((run(), _snapshot(c, K, N, mc)))
+            c.set_seed(41)                                   # rewind: run 0 again
+            out.append((run(), _snapshot(c, K, N, mc)))
+            out.append((run(), _snapshot(c, K, N, mc)))
+        return out
+
+    one, ahead = sequence(1), sequence(4)
+    assert len(one) == len(ahead) == 16
+    tol = 0.0 if mc else 2.0 / N          # GMM moments are summed over another block layout when batched
+    for i, ((p1, s1), (p2, s2)) in enumerate(zip(one, ahead)):
+        assert abs(p1 - p2) <= tol, i
+        assert s2["bp"] == [p2], i                           # the caller asked for one run at a time
+        if mc:
+            assert _same(s1, s2), i
+        else:
+            assert np.array_equal(s1["app"], s2["app"]) and np.array_equal(s1["z"], s2["z"]) and np.array_equal(s1["mu"], s2["mu"]), i
+            assert np.array_equal(s1["m7"][:, :2], s2["m7"][:, :2]), i            # survivor / collision counts
+            assert np.allclose(s1["m55"], s2["m55"], rtol=1e-6, atol=1e-9), i
+            assert np.allclose(s1["st"], s2["st"], rtol=1e-5, atol=1e-9), i
+            assert np.mean(s1["flags"] != s2["flags"]) < 1e-3 and np.allclose(s1["xyz"], s2["xyz"], atol=1e-6), i
+    assert one[14][0] == one[0][0] and ahead[14][0] == ahead[0][0]               # after the rewind
+    assert len({p for p, _ in one[:11]}) == 11                                   # every run redraws

@@ -35,4 +35,5 @@ def test_cpp_module_replays_the_reference_sequence(demo, orc, plan, env):
     cfg = orc.config(plan, env, K=3)
     assert abs(float(res["GMM"]) - orc.run_gmm(cfg, 99, 3000)["prob"]) < 1e-12
     assert float(res["MC"]) == orc.run_mc(cfg, 99, 3000)[0] / 3000
-    assert res["BADCMD"] == "0" and int(res["HELPLINES"]) == 19
+    assert res["AHEAD"] == "1"          # 6 commands served from two launches of 4 == 6 launches of 1
+    assert res["BADCMD"] == "0" and int(res["HELPLINES"]) == 21
