@@ -542,3 +542,20 @@ def test_run_ahead_serves_the_same_runs(pocs, plan, env, mc):
             assert np.mean(s1["flags"] != s2["flags"]) < 1e-3 and np.allclose(s1["xyz"], s2["xyz"], atol=1e-6), i
     assert one[14][0] == one[0][0] and ahead[14][0] == ahead[0][0]               # after the rewind
     assert len({p for p, _ in one[:11]}) == 11                                   # every run redraws
+
+
+def test_run_ahead_with_alternating_paths(pocs, plan, env):
+    """GMM and MC calls interleaved: each call consumes one run index, whether or not the previous
+    call left cached runs of the other path behind."""
+    def sequence(run_ahead):
+        with pocs.Context(0) as c:
+            c.configure(plan, env, K=2, N=3000, seed=9)
+            c.set_num_particles(3000)
+            c.set_option(pocs.OPT_RUN_AHEAD, run_ahead)
+            out = []
+            for call in "GGMGMMMGG":
+                out.append(c.run_gmm_estimation() if call == "G" else c.run_simulation())
+            return out
+    one, ahead = sequence(1), sequence(4)
+    assert all(abs(a - b) <= 2.0 / 3000 for a, b in zip(one, ahead))
+    assert [a for a, k in zip(one, "GGMGMMMGG") if k == "M"] == [a for a, k in zip(ahead, "GGMGMMMGG") if k == "M"]
