@@ -672,6 +672,11 @@ int enqueue_mc_all(pocs_ctx* c, long long first, long long count, bool prof) {
   a.total = (unsigned long long*)c->d_total.p;
   a.first = first; a.count = count; a.stride = sample_stride_of(count);
   a.W = W; a.nruns = R;
+  // 28 B of state per particle.  Up to 8 x 10^6 particles (224 MB) the state of a batch stays in the
+  // 256 MB Infinity Cache between waypoint launches; past that the launches stream from HBM whatever
+  // they do, and non-temporal accesses then stream faster (16 x 10^6: 148 us instead of 189 us)
+  a.nontemporal = ((double)R * (double)a.stride * 28.0 > 232.0e6) ? 1 : 0;
+  if (const char* e = getenv("POCS_MC_NT")) a.nontemporal = atoi(e) ? 1 : 0;          // sweeps
   a.mu0[0] = c->traj[0]; a.mu0[1] = c->traj[W]; a.mu0[2] = c->traj[2 * W];
   if (!pocs_chol3_lower(c->cov0, a.L0)) return fail(c, POCS_E_ARG, "initial covariance is not positive definite");
   HIPCHK(c, hipMemsetAsync(c->d_total.p, 0, (size_t)R * sizeof(unsigned long long), c->stream));

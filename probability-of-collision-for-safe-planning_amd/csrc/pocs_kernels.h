@@ -76,6 +76,7 @@ struct pocs_mc_launch {               // blockIdx.y = run of the batch, like poc
   double L0[6];
   int step;                            // k_mc_step: control index; k_mc_fused: number of steps
   int nruns;
+  int nontemporal;                     // k_mc_step: the batch's state exceeds the Infinity Cache, stream past it
 };
 
 hipError_t pocs_launch_gmm_step(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);

@@ -455,6 +455,11 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_init(pocs_mc_launch a) {
   }
 }
 
+// NT: non-temporal accesses, chosen by the host when the particle state of the batch does not fit
+// the 256 MB Infinity Cache anyway (the stream then runs faster past the caches; when it does fit,
+// plain accesses keep it there between waypoint launches).  One particle per thread and iteration:
+// a two-particle version with 16-byte accesses measured 12 % slower in cache, 7 % faster out of it.
+template <bool NT>
 __global__ __launch_bounds__(POCS_BLOCK) void k_mc_step(pocs_mc_launch a) {
   __shared__ double s_obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
   __shared__ pocs_footprint s_fp;
@@ -470,13 +475,19 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_step(pocs_mc_launch a) {
   const double u0 = u[0], u1 = u[1], u2 = u[2];
   const long long stride = (long long)gridDim.x * POCS_BLOCK;
   for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < a.count; i += stride) {
-    const double x = v.x[i], y = v.y[i], t = v.th[i];
+    const double x = NT ? __builtin_nontemporal_load(v.x + i) : v.x[i];
+    const double y = NT ? __builtin_nontemporal_load(v.y + i) : v.y[i];
+    const double t = NT ? __builtin_nontemporal_load(v.th + i) : v.th[i];
     double sn, cs;
     pocs_sincos(t + u0, &sn, &cs);
     const double nx = fma(u1, cs, x);
     const double ny = fma(u1, sn, y);
     const double nt = pocs_wrap_angle(t + u0 + u2);
-    v.x[i] = nx; v.y[i] = ny; v.th[i] = nt;
+    if (NT) {
+      __builtin_nontemporal_store(nx, v.x + i); __builtin_nontemporal_store(ny, v.y + i); __builtin_nontemporal_store(nt, v.th + i);
+    } else {
+      v.x[i] = nx; v.y[i] = ny; v.th[i] = nt;
+    }
     if (pocs_pose_collides(nx, ny, nt, &fp, s_obs, M, &s_tab)) v.hits[i] += 1u;
   }
 }
@@ -572,14 +583,25 @@ hipError_t pocs_launch_gmm_step(int K, int nblk, const pocs_gmm_launch& a, hipSt
   }
 }
 
-// Plain streaming copy (16 B per lane per access): the measured HBM ceiling the streaming kernels
-// are compared with next to the datasheet peak (bench.py "copy_GBps").
+// Plain streaming copy: the measured HBM ceiling the streaming kernels are compared with next to
+// the datasheet peak (bench.py "copy_GBps").  Four 16-byte non-temporal loads in flight per lane,
+// 8192 blocks: the best of the variants in tools/ubench/copy_rates.hip (6.0-6.2 TB/s read + written;
+// one plain load per lane on 2048 blocks stops at 4.9).
 __global__ __launch_bounds__(POCS_BLOCK) void k_copy(const double2* __restrict__ src, double2* __restrict__ dst, long long n) {
-  const long long stride = (long long)gridDim.x * POCS_BLOCK;
-  for (long long i = (long long)blockIdx.x * POCS_BLOCK + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const v2d* s = reinterpret_cast<const v2d*>(src);
+  v2d* d = reinterpret_cast<v2d*>(dst);
+  const long long stride = (long long)gridDim.x * POCS_BLOCK * 4;
+  for (long long i = (long long)blockIdx.x * POCS_BLOCK * 4 + threadIdx.x; i < n; i += stride) {
+    v2d v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i + u * POCS_BLOCK < n) v[u] = __builtin_nontemporal_load(s + i + u * POCS_BLOCK);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i + u * POCS_BLOCK < n) __builtin_nontemporal_store(v[u], d + i + u * POCS_BLOCK);
+  }
 }
 hipError_t pocs_launch_copy(const void* src, void* dst, long long bytes, hipStream_t s) {
-  hipLaunchKernelGGL(k_copy, dim3(2048), dim3(POCS_BLOCK), 0, s, (const double2*)src, (double2*)dst, bytes / 16);
+  hipLaunchKernelGGL(k_copy, dim3(8192), dim3(POCS_BLOCK), 0, s, (const double2*)src, (double2*)dst, bytes / 16);
   return hipGetLastError();
 }
 
@@ -592,7 +614,8 @@ hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s)
   return hipGetLastError();
 }
 hipError_t pocs_launch_mc_step(int nblk, const pocs_mc_launch& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_mc_step, dim3(nblk, a.nruns), dim3(POCS_BLOCK), 0, s, a);
+  if (a.nontemporal) hipLaunchKernelGGL(k_mc_step<true>, dim3(nblk, a.nruns), dim3(POCS_BLOCK), 0, s, a);
+  else               hipLaunchKernelGGL(k_mc_step<false>, dim3(nblk, a.nruns), dim3(POCS_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 hipError_t pocs_launch_mc_fused(int nblk, const pocs_mc_launch& a, hipStream_t s) {
