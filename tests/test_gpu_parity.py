@@ -559,3 +559,23 @@ def test_run_ahead_with_alternating_paths(pocs, plan, env):
     one, ahead = sequence(1), sequence(4)
     assert all(abs(a - b) <= 2.0 / 3000 for a, b in zip(one, ahead))
     assert [a for a, k in zip(one, "GGMGMMMGG") if k == "M"] == [a for a, k in zip(ahead, "GGMGMMMGG") if k == "M"]
+
+
+def test_mc_nontemporal_instantiation_matches(ctx, orc, plan, env, monkeypatch):
+    """k_mc_step<NT>: the instantiation the host selects once a batch's particle state exceeds the
+    Infinity Cache (too big for this suite), forced here through the sweep override: same hit
+    counters and particles as the oracle, and as the plain instantiation."""
+    N = 5001
+    cfg = orc.config(plan, env, K=1)
+    results = {}
+    for nt in ("0", "1"):
+        monkeypatch.setenv("POCS_MC_NT", nt)
+        ctx.configure(plan, env, K=1, N=N, seed=SEED + 7)       # a setter: the launch graph is captured again
+        ctx.set_num_particles(N)
+        p = ctx.run_simulation()
+        xyz, hits = ctx.particles(N)
+        results[nt] = (p, xyz.copy(), hits.copy())
+    n_mc, want_hits, _ = orc.run_mc(cfg, SEED + 7, N)
+    for nt in ("0", "1"):
+        assert results[nt][0] == n_mc / N and np.array_equal(results[nt][2], want_hits)
+    assert np.array_equal(results["0"][1], results["1"][1])
