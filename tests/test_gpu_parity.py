@@ -579,3 +579,27 @@ def test_mc_nontemporal_instantiation_matches(ctx, orc, plan, env, monkeypatch):
     for nt in ("0", "1"):
         assert results[nt][0] == n_mc / N and np.array_equal(results[nt][2], want_hits)
     assert np.array_equal(results["0"][1], results["1"][1])
+
+
+def test_default_bench_shape_properties(pocs, plan, env):
+    """The shape bench.py runs by default (64 runs of 10^6 samples per launch, K = 3), read back run
+    by run through run-ahead: every sample counted exactly once at every waypoint, finite sums,
+    live mixtures, F1 consistent, and the 64 runs all different."""
+    N, K, R = 1_000_000, 3, 64
+    with pocs.Context(0) as c:
+        c.configure(plan, env, K=K, N=N, seed=SEED)
+        c.set_option(pocs.OPT_RUN_AHEAD, R)
+        ps = []
+        for r in range(R):
+            p = c.run_gmm_estimation()
+            probs = c.waypoint_probabilities()
+            assert abs(p - (1.0 - np.prod(1.0 - probs))) < 1e-12
+            for w in (0, 31, 55):
+                m = c.moments(w, K)
+                assert np.all(np.isfinite(m)) and m[:, 0].sum() + m[:, 1].sum() == N
+                assert abs(m[:, 1].sum() / N - probs[w]) == 0.0
+            _, covs, wts, alive = c.gmm_state(55, K)
+            assert abs(wts.sum() - 1.0) < 1e-12 and np.all(alive == 1.0)
+            ps.append(p)
+        assert len(set(ps)) == R and all(0.0 < p < 1.0 for p in ps)
+        assert abs(np.mean(ps) - 0.2857) < 0.02          # the band of profiles/r01_table1_like.txt (GMM3)
