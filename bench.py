@@ -59,7 +59,7 @@ def cpu_baseline(plan, env, K, W, path, budget_evals):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0,
