@@ -8,11 +8,12 @@
 
 #define POCS_BLOCK 256        // MC kernels
 // k_gmm_step: ONE block per CU, as many waves as the register budget of the instantiation allows:
-// K <= 3 needs <= 170 VGPRs -> 12 waves (three per SIMD), K >= 4 holds 11 K accumulators -> 8 waves.
+// K = 1 needs <= 128 VGPRs -> 16 waves (four per SIMD), K <= 3 <= 170 -> 12 waves (three per SIMD),
+// K >= 4 holds 11 K accumulators -> 8 waves.
 #ifdef POCS_GMM_BLOCK                      // sweeps: force one size for every K
 #define POCS_GMM_BLOCK_OF(K) (POCS_GMM_BLOCK)
 #else
-#define POCS_GMM_BLOCK_OF(K) ((K) <= 3 ? 768 : 512)
+#define POCS_GMM_BLOCK_OF(K) ((K) == 1 ? 1024 : (K) <= 3 ? 768 : 512)
 #endif
 #define POCS_MAX_BLOCKS 2048
 // chain record (doubles), one per step i < W-1:
