@@ -78,6 +78,17 @@ class Oracle:
     def log_unit32(self, w):
         return self.lib.orc_log_unit32(C.c_uint32(w))
 
+    def component_counts(self, K, state, seed, waypoint, n_total):
+        state = np.ascontiguousarray(state, np.float64)
+        out = np.zeros(K)
+        self.lib.orc_component_counts(C.c_int(K), _p(state), C.c_uint64(seed), C.c_int(waypoint), C.c_longlong(n_total), _p(out))
+        return out
+
+    def binomial(self, n, p, seed, comp=0, waypoint=0):
+        self.lib.orc_binomial.restype = C.c_double
+        self.lib.orc_binomial.argtypes = [C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32]
+        return self.lib.orc_binomial(float(n), float(p), int(seed), int(comp), int(waypoint))
+
     def normal_pair_w2(self, wr, wa):
         a, b = C.c_double(), C.c_double()
         self.lib.orc_normal_pair_w2(C.c_uint32(wr), C.c_uint32(wa), C.byref(a), C.byref(b))
@@ -219,14 +230,16 @@ class Oracle:
         self.lib.orc_gmm_initial_state(C.byref(cfg), _p(s))
         return s
 
-    def gmm_waypoint(self, cfg, seed, w, state, first, count, want_samples=False):
+    def gmm_waypoint(self, cfg, seed, w, state, first, count, want_samples=False, n_total=None):
+        """n_total: samples of the whole mixture (the component counts add up to it); default = the shard."""
+        n_total = first + count if n_total is None else n_total
         state = np.ascontiguousarray(state, np.float64)
         mom = np.zeros((cfg.K, NMOM))
         samples = np.zeros((max(count, 1), 3)) if want_samples else None
         flags = np.zeros(max(count, 1), np.int16) if want_samples else None
         comp = np.zeros(max(count, 1), np.int8) if want_samples else None
         self.lib.orc_gmm_waypoint(C.byref(cfg), C.c_uint64(seed), C.c_int(w), _p(state),
-                                  C.c_longlong(first), C.c_longlong(count), _p(mom), _p(samples),
+                                  C.c_longlong(first), C.c_longlong(count), C.c_longlong(n_total), _p(mom), _p(samples),
                                   None if flags is None else flags.ctypes.data_as(C.POINTER(C.c_int16)),
                                   None if comp is None else comp.ctypes.data_as(C.POINTER(C.c_int8)))
         if want_samples:

@@ -292,6 +292,90 @@ void orc_sample_normals(uint64_t seed, uint64_t sample, uint32_t waypoint, uint3
   }
 }
 
+/* ---- component counts: Multinomial(N, weights) by conditional binomials ------------------------
+ * The reference counts N categorical draws (GM_Model.h:87-93).  Bin(n, p): waiting times when
+ * n min(p,1-p) < 10, else BTPE (Kachitvichyanukul & Schmeiser, CACM 31(2), 1988).  Uniforms: 53 bits
+ * of two words of a draw on stream 4, counter = (component, 0, waypoint, 4 << 16 | draw number). */
+typedef struct { uint64_t seed; uint32_t comp, waypoint, draw; uint32_t w[4]; int have; } count_rng;
+
+static double count_uniform(count_rng* g) {
+  if (g->have == 0) { draw(g->seed, (uint64_t)g->comp, g->waypoint, 4, g->draw, g->w); g->draw += 1; g->have = 2; }
+  uint32_t lo = (g->have == 2) ? g->w[0] : g->w[2], hi = (g->have == 2) ? g->w[1] : g->w[3];
+  g->have -= 1;
+  uint64_t m = (((uint64_t)hi << 32) | lo) >> 11;
+  return ((double)m + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+double orc_binomial(double n, double p, uint64_t seed, uint32_t comp, uint32_t waypoint) {
+  count_rng g; g.seed = seed; g.comp = comp; g.waypoint = waypoint; g.draw = 0; g.have = 0;
+  if (!(n >= 1.0) || !(p > 0.0)) return 0.0;
+  if (p >= 1.0) return n;
+  int flip = p > 0.5;
+  double r = flip ? 1.0 - p : p, q = 1.0 - r, y;
+  if (n * r < 10.0) {
+    double lq = orc_log(q), pos = 0.0;
+    y = 0.0;
+    for (int it = 0; it < 400; ++it) {
+      pos += floor(orc_log(count_uniform(&g)) / lq) + 1.0;
+      if (pos > n) break;
+      y += 1.0;
+    }
+    return flip ? n - y : y;
+  }
+  double nrq = n * r * q, fm = n * r + r, m = floor(fm);
+  double p1 = floor(2.195 * sqrt(nrq) - 4.6 * q) + 0.5;
+  double xm = m + 0.5, xl = xm - p1, xr = xm + p1;
+  double c = 0.134 + 20.5 / (15.3 + m);
+  double a = (fm - xl) / (fm - xl * r);
+  double laml = a * (1.0 + a / 2.0);
+  a = (xr - fm) / (xr * q);
+  double lamr = a * (1.0 + a / 2.0);
+  double p2 = p1 * (1.0 + 2.0 * c), p3 = p2 + c / laml, p4 = p3 + c / lamr;
+  y = m;
+  for (int it = 0; it < 1000; ++it) {
+    double u = count_uniform(&g) * p4;
+    double v = count_uniform(&g);
+    if (u <= p1) { y = floor(xm - p1 * v + u); break; }
+    if (u <= p2) {
+      double x = xl + (u - p1) / c;
+      v = v * c + 1.0 - fabs(m - x + 0.5) / p1;
+      if (v > 1.0) continue;
+      y = floor(x);
+    } else if (u <= p3) {
+      y = floor(xl + orc_log(v) / laml);
+      if (y < 0.0) continue;
+      v = v * (u - p2) * laml;
+    } else {
+      y = floor(xr - orc_log(v) / lamr);
+      if (y > n) continue;
+      v = v * (u - p3) * lamr;
+    }
+    double k = fabs(y - m);
+    if (k > 20.0 && k < nrq / 2.0 - 1.0) {
+      double rho = (k / nrq) * ((k * (k / 3.0 + 0.625) + 0.16666666666666666) / nrq + 0.5);
+      double t = -k * k / (2.0 * nrq);
+      double A = orc_log(v);
+      if (A < t - rho) break;
+      if (A > t + rho) continue;
+      double x1 = y + 1.0, f1 = m + 1.0, z = n + 1.0 - m, w = n - y + 1.0;
+      double x2 = x1 * x1, f2 = f1 * f1, z2 = z * z, w2 = w * w;
+      double bound = xm * orc_log(f1 / x1) + (n - m + 0.5) * orc_log(z / w) + (y - m) * orc_log(w * r / (x1 * q)) +
+                     (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / f2) / f2) / f2) / f2) / f1 / 166320.0 +
+                     (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / z2) / z2) / z2) / z2) / z / 166320.0 +
+                     (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / x2) / x2) / x2) / x2) / x1 / 166320.0 +
+                     (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / w2) / w2) / w2) / w2) / w / 166320.0;
+      if (A > bound) continue;
+      break;
+    }
+    double s = r / q, aa = s * (n + 1.0), F = 1.0;
+    if (m < y) { for (double i = m + 1.0; i <= y; i += 1.0) F *= (aa / i - s); }
+    else if (m > y) { for (double i = y + 1.0; i <= m; i += 1.0) F /= (aa / i - s); }
+    if (v > F) continue;
+    break;
+  }
+  return flip ? n - y : y;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* estimator math                                                                              */
 /* ------------------------------------------------------------------------------------------ */
@@ -601,24 +685,45 @@ long long orc_run_mc(const orc_config* cfg, uint64_t seed, long long first, long
  * draw per sample (GM_Model.h:89-93 draws N of them and counts; drawing it next to the sample
  * gives the same joint law and keeps a sample's randomness a function of its index).
  * samples_out (count x 3), flags_out (count), comp_out (count) optional. */
+/* counts[k] of the n_total samples of a waypoint, as their running sum: Multinomial(n_total,
+ * weights) like the reference's N categorical draws (GM_Model.h:87-93), drawn as conditional
+ * binomials in component order; retired components get none; all retired: component 0 gets all. */
+void orc_component_counts(int K, const double* state, uint64_t seed, int waypoint, long long n_total,
+                          double* cumulative) {
+  int last_alive = -1;
+  double suffix[ORC_MAX_K], tail = 0.0;
+  for (int k = K - 1; k >= 0; --k) {
+    const double* st = state + k * ORC_STATE;
+    int live = st[13] != 0.0 && st[12] > 0.0;
+    if (live) { tail += st[12]; if (last_alive < 0) last_alive = k; }
+    suffix[k] = tail;
+  }
+  double remaining = (double)n_total, running = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const double* st = state + k * ORC_STATE;
+    double nk = 0.0;
+    if (last_alive < 0) nk = (k == 0) ? remaining : 0.0;
+    else if (k == last_alive) nk = remaining;
+    else if (k < last_alive && st[13] != 0.0 && st[12] > 0.0)
+      nk = orc_binomial(remaining, st[12] / suffix[k], seed, (uint32_t)k, (uint32_t)waypoint);
+    remaining -= nk;
+    running += nk;
+    cumulative[k] = running;
+  }
+}
+
 int orc_gmm_waypoint(const orc_config* cfg, uint64_t seed, int waypoint, const double* state,
-                     long long first, long long count, double* moments, double* samples_out,
-                     int16_t* flags_out, int8_t* comp_out) {
+                     long long first, long long count, long long n_total, double* moments,
+                     double* samples_out, int16_t* flags_out, int8_t* comp_out) {
   int K = cfg->K;
   double chol[ORC_MAX_K][6];
   double table[ORC_MAX_K];
-  int last_alive = -1;
-  double running = 0.0;
   for (int k = 0; k < K; ++k) {
     const double* st = state + k * ORC_STATE;
     memset(chol[k], 0, sizeof chol[k]);
     if (st[13] != 0.0) orc_chol3_lower(st + 3, chol[k]);
-    if (st[13] != 0.0 && st[12] > 0.0) last_alive = k;
   }
-  for (int k = 0; k < K; ++k) {
-    running += state[k * ORC_STATE + 12];
-    table[k] = (k >= last_alive) ? 2.0 : running;
-  }
+  orc_component_counts(K, state, seed, waypoint, n_total, table);
   /* the reference keeps one matrix of points per component (GM_Model.h:99-107) and takes
    * mean / cov of the free columns afterwards (MCSimulator.h:592-598); do the same. */
   double* free_pts[ORC_MAX_K];
@@ -631,9 +736,10 @@ int orc_gmm_waypoint(const orc_config* cfg, uint64_t seed, int waypoint, const d
     double zz[3];
     uint32_t spare;
     orc_sample_normals(seed, (uint64_t)(first + i), (uint32_t)waypoint, 3 /* gmm stream */, zz, &spare);
-    double uc = ((double)spare + 0.5) * (1.0 / 4294967296.0);
+    (void)spare;
+    double gidx = (double)(first + i);                /* component = first one whose running count exceeds the index */
     int k = 0;
-    for (int j = 0; j < K - 1; ++j) if (table[j] < uc) ++k;
+    for (int j = 0; j < K - 1; ++j) if (table[j] <= gidx) ++k;
     const double* st = state + k * ORC_STATE;
     const double* Lk = chol[k];
     double pt[3];                                                       /* mvnrnd: D*z + M */
@@ -744,7 +850,7 @@ double orc_run_gmm(const orc_config* cfg, uint64_t seed, long long N, double* pr
   for (int w = 0; w < W; ++w) {
     int last = (w == W - 1);
     if (states_out) memcpy(states_out + (size_t)w * K * ORC_STATE, state, sizeof(double) * K * ORC_STATE);
-    orc_gmm_waypoint(cfg, seed, w, state, 0, N, mom, last ? last_samples : NULL,
+    orc_gmm_waypoint(cfg, seed, w, state, 0, N, N, mom, last ? last_samples : NULL,
                      last ? last_flags : NULL, NULL);
     if (moments_out) memcpy(moments_out + (size_t)w * K * ORC_NMOM, mom, sizeof(double) * K * ORC_NMOM);
     double collided = 0.0;

@@ -524,7 +524,7 @@ void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long
   a->ticket = (unsigned*)c->d_ticket.p;
   a->x = (double*)c->d_sx.p; a->y = (double*)c->d_sy.p; a->th = (double*)c->d_st.p;
   a->flags = (int16_t*)c->d_flags.p;
-  a->first = first; a->count = count;
+  a->first = first; a->count = count; a->n_total = c->num_gmm;
   a->fp = c->fp; a->M = (int)(c->boxes.size() / 5);
   a->waypoint = w; a->store = c->opt_store ? 1 : 0;
   a->sample_stride = sample_stride_of(count);

@@ -44,12 +44,13 @@ struct pocs_gmm_launch {
   const double* chain;           // [nruns][W-1][POCS_CHAIN_STRIDE]
   const pocs_sensor* sensor;
   double* state;                 // [nruns][W][K*POCS_STATE_STRIDE]  mixture sampled at each waypoint
-  double* param;                 // [nruns][W][K*POCS_PARAM_STRIDE]  its sampler parameters
+  double* param;                 // [nruns][W][K*POCS_PARAM_STRIDE]  its sampler parameters (incl. the cumulative component counts)
   double* moments;               // [W][nruns][K*POCS_NMOM]          reduced moments of each waypoint
   double* partial;               // [nruns][gridDim.x][K*POCS_NMOM]  block partials of this launch
   unsigned* ticket;              // [nruns][W] arrival counters, zeroed once per batch
   double* x; double* y; double* th;   // SoA sample buffers [nruns][sample_stride] (unused when !store)
   int16_t* flags;
+  long long n_total;             // samples of the whole mixture (all shards): what the component counts add up to
   long long first;               // global index of the shard's first sample
   long long count;               // samples in this shard
   long long sample_stride;       // even, >= count

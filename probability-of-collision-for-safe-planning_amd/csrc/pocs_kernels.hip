@@ -139,7 +139,7 @@ __device__ __forceinline__ void advance_mixture(const pocs_gmm_launch& a, int K,
                                reinterpret_cast<const pocs_sensor*>(l_sen), l_next, l_par);
   __threadfence_block();
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) pocs_gmm_normalise(K, w > 0, l_next, l_par);
+  if (lane == 0) pocs_gmm_normalise(K, w > 0, l_next, l_par, a.hdr[r].seed, (uint32_t)w, (double)a.n_total);
   __threadfence_block();
   __builtin_amdgcn_wave_barrier();
   for (int j = lane; j < ss; j += 64) g_state[(size_t)w * ss + j] = l_next[j];
@@ -242,6 +242,10 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
   const long long stride = (long long)gridDim.x * TB;
   const long long npairs = (a.count + 1) >> 1;
   const uint64_t pair0 = (uint64_t)(a.first >> 1);
+  const double first_d = (double)a.first;
+  double cumn[K > 1 ? K - 1 : 1];                   // cumulative component counts (wave-uniform)
+#pragma unroll
+  for (int j = 0; j < K - 1; ++j) cumn[j] = s_par[j * POCS_PARAM_STRIDE + 9];
   // The loop counter is wave-uniform (SGPRs) and the lane adds its tid: the store addresses are a
   // scalar base per iteration plus a constant 16*tid, no per-lane 64-bit address arithmetic.
   double* const xr = a.x + (size_t)r * a.sample_stride;          // this run's slice (sample_stride is even)
@@ -271,15 +275,18 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
 #endif
     const long long i0 = 2 * lp;
     const bool two = (i0 + 1) < a.count;          // false only for the last sample of an odd shard
+    const double gbase = first_d + (double)i0;     // global index of sample 2*lp (exact: < 2^53)
     double xs[2], ys[2], ts[2];
     bool hits[2];
+    int ks[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      // component draw (GM_Model.h:89-93): number of cumulative-weight entries below the uniform
-      const double uc = ((double)spare[h] + 0.5) * 0x1p-32;
+      // component of the sample (GM_Model.h:87-107: counts[k] samples per component, one block
+      // after the other): the first component whose cumulative count exceeds the global index
+      const double gidx = gbase + (double)h;
       int k = 0;
 #pragma unroll
-      for (int j = 0; j < K - 1; ++j) k += (s_par[j * POCS_PARAM_STRIDE + 9] < uc) ? 1 : 0;
+      for (int j = 0; j < K - 1; ++j) k += (cumn[j] <= gidx) ? 1 : 0;
       const double* p = &s_par[k * POCS_PARAM_STRIDE];
       // mvnrnd (glue_mvnrnd_meat.hpp:134-145): chol_lower * z + mean
       const double x = fma(p[3], zz[h][0], p[0]);
@@ -290,33 +297,42 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
 #else
       const bool hit = pocs_pose_collides(x, y, t, &fp, s_keep, nkeep, &s_tab);
 #endif
-      xs[h] = x; ys[h] = y; ts[h] = t; hits[h] = hit;
-      // T1 sums: acc_k += ind_k * (x, y, t, xx, xy, xt, yy, yt, tt) with ind_k = 1.0 for the
-      // sample's own component when it is collision free, else 0.0; fma(1, v, acc) == acc + v and
-      // fma(0, v, acc) == acc exactly, so this is the masked sum without the select instructions.
-      const bool valid = (h == 0) || two;
+      xs[h] = x; ys[h] = y; ts[h] = t; hits[h] = hit; ks[h] = k;
+    }
 #if defined(POCS_ABLATE_MOMENTS)
-      acc[0][0] += x + y + t; nfree[0] += hit ? 0u : 1u; ncoll[0] += (valid && k == 0) ? 1u : 0u;
+    acc[0][0] += xs[0] + ys[0] + ts[0] + xs[1]; nfree[0] += hits[0] ? 0u : 1u; ncoll[0] += (two && ks[1] == 0) ? 1u : 0u;
 #else
-      const double xx = x * x, xy = x * y, xt = x * t, yy = y * y, yt = y * t, tt = t * t;
+    // T1 sums: acc_k += ind * (x, y, t, xx, xy, xt, yy, yt, tt) with ind = 1.0 for a collision-free
+    // sample of component k, else 0.0 (fma(1, v, acc) == acc + v, fma(0, v, acc) == acc exactly).
+    // Samples come in component blocks, so a wave sits in ONE component except where two blocks
+    // meet: then only that component's sums are touched, chosen by scalar compares; the general
+    // form (every component, per-lane indicator) serves the few waves that straddle a boundary.
+    {
+      const int ku = __builtin_amdgcn_readfirstlane(ks[0]);
+      const bool uniform = __ballot(ks[0] != ku || ks[1] != ku) == 0ull;
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
-        const bool sel = valid && (k == kk);
-        nfree[kk] += (sel && !hit) ? 1u : 0u;
-        ncoll[kk] += (sel && hit) ? 1u : 0u;
-        const double ind = (sel && !hit) ? 1.0 : 0.0;
-        acc[kk][0] = fma(ind, x, acc[kk][0]);
-        acc[kk][1] = fma(ind, y, acc[kk][1]);
-        acc[kk][2] = fma(ind, t, acc[kk][2]);
-        acc[kk][3] = fma(ind, xx, acc[kk][3]);
-        acc[kk][4] = fma(ind, xy, acc[kk][4]);
-        acc[kk][5] = fma(ind, xt, acc[kk][5]);
-        acc[kk][6] = fma(ind, yy, acc[kk][6]);
-        acc[kk][7] = fma(ind, yt, acc[kk][7]);
-        acc[kk][8] = fma(ind, tt, acc[kk][8]);
+        if (uniform ? (ku != kk) : false) continue;                  // scalar: skip the other components
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool sel = ((h == 0) || two) && (uniform || ks[h] == kk);
+          const double x = xs[h], y = ys[h], t = ts[h];
+          nfree[kk] += (sel && !hits[h]) ? 1u : 0u;
+          ncoll[kk] += (sel && hits[h]) ? 1u : 0u;
+          const double ind = (sel && !hits[h]) ? 1.0 : 0.0;
+          acc[kk][0] = fma(ind, x, acc[kk][0]);
+          acc[kk][1] = fma(ind, y, acc[kk][1]);
+          acc[kk][2] = fma(ind, t, acc[kk][2]);
+          acc[kk][3] = fma(ind, x * x, acc[kk][3]);
+          acc[kk][4] = fma(ind, x * y, acc[kk][4]);
+          acc[kk][5] = fma(ind, x * t, acc[kk][5]);
+          acc[kk][6] = fma(ind, y * y, acc[kk][6]);
+          acc[kk][7] = fma(ind, y * t, acc[kk][7]);
+          acc[kk][8] = fma(ind, t * t, acc[kk][8]);
+        }
       }
-#endif
     }
+#endif
     if (STORE) {
       // Both poses of the pair leave together.  For the last sample of an odd shard the second
       // slot is the pair's unused twin: it lands in the padding element of the run's slice

@@ -153,6 +153,112 @@ POCS_HD int pocs_truncated_moments(const double* mom, double mean[3], double cov
   return 1;
 }
 
+// ----------------------------------------------------------------------------------------------
+// Component counts of a waypoint: how many of the N samples each component of the mixture gets.
+// The reference draws N categorical indices and counts them (GM_Model.h:87-93), i.e. the counts
+// are Multinomial(N, weights), and then generates counts[k] samples per component as one block
+// (:99-107).  Drawing the counts directly -- K-1 conditional binomials -- gives the same law and
+// makes a sample's component a function of its index, so a wave works on one component at a time.
+//
+// pocs_binomial(n, p): Bin(n, p) for 0 <= n < 2^53 held in a double.  n*min(p,1-p) < 10: waiting
+// times (sum of geometric gaps, floor(log U / log q) + 1).  Otherwise BTPE (Kachitvichyanukul &
+// Schmeiser, "Binomial random variate generation", CACM 31(2), 1988): triangle / parallelogram /
+// exponential-tail envelope, squeeze, Stirling-corrected final test.  Uniforms: 53 bits from two
+// words, (m + 1/2) 2^-53 in (0, 1), drawn from Philox stream POCS_STREAM_COUNTS with
+// counter = (component, 0, waypoint, stream << 16 | draw number).
+// ----------------------------------------------------------------------------------------------
+#define POCS_STREAM_COUNTS 4u
+
+struct pocs_count_rng { uint64_t seed; uint32_t comp, waypoint, draw; pocs_u32x4 w; int have; };
+
+POCS_HD double pocs_count_uniform(pocs_count_rng* g) {
+  if (g->have == 0) { g->w = pocs_draw(g->seed, (uint64_t)g->comp, g->waypoint, POCS_STREAM_COUNTS, g->draw); g->draw += 1u; g->have = 2; }
+  const uint32_t lo = (g->have == 2) ? g->w.x : g->w.z, hi = (g->have == 2) ? g->w.y : g->w.w;
+  g->have -= 1;
+  const uint64_t m = ((((uint64_t)hi) << 32) | (uint64_t)lo) >> 11;
+  return ((double)m + 0.5) * 0x1p-53;
+}
+
+POCS_HD double pocs_binomial(double n, double p, pocs_count_rng* g) {
+  if (!(n >= 1.0) || !(p > 0.0)) return 0.0;
+  if (p >= 1.0) return n;
+  const bool flip = p > 0.5;
+  const double r = flip ? 1.0 - p : p;
+  const double q = 1.0 - r;
+  double y;
+  if (n * r < 10.0) {
+    // waiting times: the successes sit at positions G1, G1+G2, ...; count those <= n
+    const double lq = pocs_log(q);
+    double pos = 0.0;
+    y = 0.0;
+    for (int it = 0; it < 400; ++it) {                 // n r < 10: more than 400 successes cannot happen in practice
+      pos += floor(pocs_log(pocs_count_uniform(g)) / lq) + 1.0;
+      if (pos > n) break;
+      y += 1.0;
+    }
+  } else {
+    const double nrq = n * r * q;
+    const double fm = n * r + r;
+    const double m = floor(fm);
+    const double p1 = floor(2.195 * sqrt(nrq) - 4.6 * q) + 0.5;
+    const double xm = m + 0.5, xl = xm - p1, xr = xm + p1;
+    const double c = 0.134 + 20.5 / (15.3 + m);
+    double a = (fm - xl) / (fm - xl * r);
+    const double laml = a * (1.0 + a / 2.0);
+    a = (xr - fm) / (xr * q);
+    const double lamr = a * (1.0 + a / 2.0);
+    const double p2 = p1 * (1.0 + 2.0 * c);
+    const double p3 = p2 + c / laml;
+    const double p4 = p3 + c / lamr;
+    y = m;
+    for (int it = 0; it < 1000; ++it) {                // acceptance > 0.7 per round: 1000 rounds never exhaust
+      const double u = pocs_count_uniform(g) * p4;
+      double v = pocs_count_uniform(g);
+      if (u <= p1) { y = floor(xm - p1 * v + u); break; }                              // triangle: accept
+      if (u <= p2) {                                                                     // parallelograms
+        const double x = xl + (u - p1) / c;
+        v = v * c + 1.0 - fabs(m - x + 0.5) / p1;
+        if (v > 1.0) continue;
+        y = floor(x);
+      } else if (u <= p3) {                                                              // left tail
+        y = floor(xl + pocs_log(v) / laml);
+        if (y < 0.0) continue;
+        v = v * (u - p2) * laml;
+      } else {                                                                           // right tail
+        y = floor(xr - pocs_log(v) / lamr);
+        if (y > n) continue;
+        v = v * (u - p3) * lamr;
+      }
+      const double k = fabs(y - m);
+      if (k > 20.0 && k < nrq / 2.0 - 1.0) {
+        // squeeze, then the final test with Stirling's correction
+        const double rho = (k / nrq) * ((k * (k / 3.0 + 0.625) + 0.16666666666666666) / nrq + 0.5);
+        const double t = -k * k / (2.0 * nrq);
+        const double A = pocs_log(v);
+        if (A < t - rho) break;
+        if (A > t + rho) continue;
+        const double x1 = y + 1.0, f1 = m + 1.0, z = n + 1.0 - m, w = n - y + 1.0;
+        const double x2 = x1 * x1, f2 = f1 * f1, z2 = z * z, w2 = w * w;
+        const double bound = xm * pocs_log(f1 / x1) + (n - m + 0.5) * pocs_log(z / w) + (y - m) * pocs_log(w * r / (x1 * q)) +
+                             (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / f2) / f2) / f2) / f2) / f1 / 166320.0 +
+                             (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / z2) / z2) / z2) / z2) / z / 166320.0 +
+                             (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / x2) / x2) / x2) / x2) / x1 / 166320.0 +
+                             (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / w2) / w2) / w2) / w2) / w / 166320.0;
+        if (A > bound) continue;
+        break;
+      }
+      // explicit evaluation of f(y)/f(m) by the recurrence
+      const double s = r / q, aa = s * (n + 1.0);
+      double F = 1.0;
+      if (m < y) { for (double i = m + 1.0; i <= y; i += 1.0) F *= (aa / i - s); }
+      else if (m > y) { for (double i = y + 1.0; i <= m; i += 1.0) F /= (aa / i - s); }
+      if (v > F) continue;
+      break;
+    }
+  }
+  return flip ? n - y : y;
+}
+
 // One waypoint of the mixture bookkeeping, split so the device can run one component per
 // thread: truncateGMM's tail (:592-629: truncated mean/cov; weights = nFree_k / sum nFree via
 // normalise(.,1,1), armadillo_bits/op_normalise_meat.hpp:107-121), then the per-component
@@ -202,8 +308,14 @@ POCS_HD void pocs_gmm_advance_component(int k, const double* prev, const double*
 }
 
 // Second half: weights and the sampler's selection table.  `renorm` = 1 when the weights in
-// `next` are raw survivor counts (every waypoint but the first).
-POCS_HD void pocs_gmm_normalise(int K, int renorm, double* next, double* param) {
+// `next` are raw survivor counts (every waypoint but the first).  The table is the cumulative
+// COUNT of samples per component for this waypoint, param[k][9] = n_0 + ... + n_k with
+// (n_0 .. n_{K-1}) ~ Multinomial(n_total, weights) drawn as conditional binomials in component
+// order (a retired component has weight 0 and gets none; if every component is retired,
+// component 0's frozen mean receives all samples): global sample i belongs to the first
+// component whose entry exceeds i.
+POCS_HD void pocs_gmm_normalise(int K, int renorm, double* next, double* param, uint64_t seed,
+                                uint32_t waypoint, double n_total) {
   double wsum = 0.0;
   for (int k = 0; k < K; ++k) wsum += next[k * POCS_STATE_STRIDE + 12];
   // normalise(collisionCounts,1,1).row(1): divide by the L1 norm, a zero norm divides by 1.
@@ -214,12 +326,27 @@ POCS_HD void pocs_gmm_normalise(int K, int renorm, double* next, double* param) 
     if (renorm) o[12] = o[12] / den;
     if (o[13] != 0.0 && o[12] > 0.0) last_alive = k;
   }
-  double cum = 0.0;
+  double suffix[POCS_MAX_GAUSSIANS];
+  double tail = 0.0;
+  for (int k = K - 1; k >= 0; --k) {
+    const double* o = next + k * POCS_STATE_STRIDE;
+    if (o[13] != 0.0 && o[12] > 0.0) tail += o[12];
+    suffix[k] = tail;
+  }
+  double rem = n_total, run = 0.0;
   for (int k = 0; k < K; ++k) {
-    cum += next[k * POCS_STATE_STRIDE + 12];
-    // selection rule: component = number of table entries strictly below the uniform draw;
-    // entries from the last live component on are pinned above 1 so rounding never selects a
-    // retired component.
-    param[k * POCS_PARAM_STRIDE + 9] = (k >= last_alive) ? 2.0 : cum;
+    const double* o = next + k * POCS_STATE_STRIDE;
+    double nk = 0.0;
+    if (last_alive < 0) {
+      nk = (k == 0) ? rem : 0.0;
+    } else if (k == last_alive) {
+      nk = rem;
+    } else if (k < last_alive && o[13] != 0.0 && o[12] > 0.0) {
+      pocs_count_rng g; g.seed = seed; g.comp = (uint32_t)k; g.waypoint = waypoint; g.draw = 0u; g.have = 0;
+      nk = pocs_binomial(rem, o[12] / suffix[k], &g);
+    }
+    rem -= nk;
+    run += nk;
+    param[k * POCS_PARAM_STRIDE + 9] = run;
   }
 }

@@ -32,6 +32,10 @@ void hh_normal3_pair(uint64_t seed, uint64_t pair, uint32_t wp, uint32_t stream,
                      uint32_t* sa, uint32_t* sb) {
   pocs_normal3_pair(seed, pair, wp, stream, tabs(), za, zb, sa, sb);
 }
+double hh_binomial(double n, double p, uint64_t seed, uint32_t comp, uint32_t wp) {
+  pocs_count_rng g; g.seed = seed; g.comp = comp; g.waypoint = wp; g.draw = 0; g.have = 0;
+  return pocs_binomial(n, p, &g);
+}
 double hh_wrap(double a) { return pocs_wrap_angle(a); }
 void hh_motion(const double* x, const double* u, double* o) { pocs_motion(x, u, o); }
 void hh_ekf_predict(const double* mu, const double* S, const double* u, const double* Md, double* pm, double* pS) {
@@ -54,12 +58,12 @@ int hh_collides(double x, double y, double th, const double* fp4, const double* 
 // prev/next: K x 16, mom: K x 11 or null, param: K x 12
 void hh_gmm_advance(int K, const double* prev, const double* mom, const double* u, const double* Md,
                     const double* z, int L, const double* lx, const double* ly, double Q,
-                    double* next, double* param) {
+                    double* next, double* param, uint64_t seed, uint32_t waypoint, double n_total) {
   pocs_sensor sen;
   std::memset(&sen, 0, sizeof sen);
   sen.Q = Q; sen.L = L;
   for (int i = 0; i < L; ++i) { sen.lx[i] = lx[i]; sen.ly[i] = ly[i]; }
   for (int k = 0; k < K; ++k) pocs_gmm_advance_component(k, prev, mom, u, Md, z, &sen, next, param);
-  pocs_gmm_normalise(K, mom != nullptr, next, param);
+  pocs_gmm_normalise(K, mom != nullptr, next, param, seed, waypoint, n_total);
 }
 }

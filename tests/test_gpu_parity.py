@@ -281,7 +281,7 @@ def test_shards_partition_the_work(ctx, orc, plan, env):
         ctx.gmm_end()
         # without the exchange only waypoint 0 is meaningful: its moments are this shard's sums
         parts.append(ctx.moments(0, 3).copy())
-        want = orc.gmm_waypoint(cfg, 21, 0, orc.gmm_advance(cfg, orc.gmm_initial_state(cfg), None), first, count)
+        want = orc.gmm_waypoint(cfg, 21, 0, orc.gmm_advance(cfg, orc.gmm_initial_state(cfg), None), first, count, n_total=N)
         close_moments(parts[-1], want)
     ctx.set_shard()
     assert np.array_equal((parts[0] + parts[1])[:, :2], whole[:, :2])

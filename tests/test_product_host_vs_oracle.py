@@ -196,22 +196,27 @@ def test_gmm_advance_matches_oracle(hh, orc, plan, env, pocs):
     chain = orc.host_chain(cfg, 77)
     state = orc.gmm_initial_state(cfg)
     nxt, par = np.zeros((3, 16)), np.zeros((3, 12))
-    hh.hh_gmm_advance(3, dp(state), None, None, None, None, 8, dp(lx), dp(ly), C.c_double(pocs.DEFAULTS["Q"]), dp(nxt), dp(par))
+    hh.hh_gmm_advance(3, dp(state), None, None, None, None, 8, dp(lx), dp(ly), C.c_double(pocs.DEFAULTS["Q"]), dp(nxt), dp(par),
+                      C.c_uint64(77), C.c_uint32(0), C.c_double(500.0))
     want = orc.gmm_advance(cfg, state, None)
     assert np.array_equal(nxt[:, :14], want[:, :14])
+    assert np.array_equal(par[:, 9], orc.component_counts(3, want, 77, 0, 500)) and par[2, 9] == 500.0
     state = want
     for w in range(6):
         mom = orc.gmm_waypoint(cfg, 77, w, state, 0, 500)
         want = orc.gmm_advance(cfg, state, mom, chain["applied"][w], chain["Mdiag"][w], chain["z"][w])
         hh.hh_gmm_advance(3, dp(state), dp(mom), dp(np.ascontiguousarray(chain["applied"][w])),
                           dp(np.ascontiguousarray(chain["Mdiag"][w])), dp(np.ascontiguousarray(chain["z"][w])),
-                          8, dp(lx), dp(ly), C.c_double(pocs.DEFAULTS["Q"]), dp(nxt), dp(par))
+                          8, dp(lx), dp(ly), C.c_double(pocs.DEFAULTS["Q"]), dp(nxt), dp(par),
+                          C.c_uint64(77), C.c_uint32(w + 1), C.c_double(500.0))
         assert np.array_equal(nxt[:, :14], want[:, :14])
         # sampler parameters: mean, Cholesky factor, selection table
         for k in range(3):
             ok, L = orc.chol3_lower(want[k, 3:12])
             assert ok and np.array_equal(par[k, 3:9], L) and np.array_equal(par[k, 0:3], want[k, 0:3])
-        assert par[2, 9] == 2.0 and par[0, 9] == want[0, 12]
+        # the selection table: cumulative component counts of waypoint w + 1, Multinomial(500, weights)
+        assert np.array_equal(par[:, 9], orc.component_counts(3, want, 77, w + 1, 500)) and par[2, 9] == 500.0
+        assert np.all(np.diff(np.concatenate([[0.0], par[:, 9]])) >= 0)
         state = want
 
 
@@ -228,11 +233,65 @@ def test_gmm_advance_retires_degenerate_components(hh, orc, plan, env, pocs):
     nxt, par = np.zeros((3, 16)), np.zeros((3, 12))
     hh.hh_gmm_advance(3, dp(state), dp(mom), dp(np.ascontiguousarray(chain["applied"][0])),
                       dp(np.ascontiguousarray(chain["Mdiag"][0])), dp(np.ascontiguousarray(chain["z"][0])),
-                      8, dp(lx), dp(ly), C.c_double(pocs.DEFAULTS["Q"]), dp(nxt), dp(par))
+                      8, dp(lx), dp(ly), C.c_double(pocs.DEFAULTS["Q"]), dp(nxt), dp(par),
+                      C.c_uint64(5), C.c_uint32(1), C.c_double(300.0))
     assert np.array_equal(nxt[:, :14], want[:, :14])
     assert list(want[:, 13]) == [1.0, 0.0, 0.0] and list(want[:, 12]) == [1.0, 0.0, 0.0]
-    assert list(par[:, 9]) == [2.0, 2.0, 2.0]   # only component 0 can be selected
+    assert list(par[:, 9]) == [300.0, 300.0, 300.0]   # only component 0 receives samples
     # all dead: weights all zero (normalise divides by 1), nothing selectable but component 0
     mom[0, :] = 0.0
     want = orc.gmm_advance(cfg, state, mom, chain["applied"][0], chain["Mdiag"][0], chain["z"][0])
     assert np.all(want[:, 12] == 0.0) and np.all(want[:, 13] == 0.0)
+
+
+def test_binomial_sampler_bitwise_and_exact_in_law(hh, orc):
+    """Bin(n, p) behind the component counts (waiting times below n min(p,1-p) = 10, BTPE above):
+    product == oracle bit for bit; chi-square against the exact pmf; mean and variance."""
+    from scipy import stats
+    hh.hh_binomial.restype = C.c_double
+    hh.hh_binomial.argtypes = [C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32]
+    rng = np.random.default_rng(3)
+    for _ in range(4000):
+        n, p = float(rng.integers(1, 10 ** 7)), float(rng.random())
+        if rng.random() < 0.3:
+            p = float(rng.choice([1e-9, 1e-6, 0.5, 1.0 - 1e-9, 0.999]))
+        seed, k, w = int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 8)), int(rng.integers(0, 500))
+        got = hh.hh_binomial(n, p, seed, k, w)
+        assert got == orc.binomial(n, p, seed, k, w) and 0.0 <= got <= n and got == math.floor(got)
+    assert orc.binomial(0, 0.3, 1) == 0.0 and orc.binomial(17, 0.0, 1) == 0.0 and orc.binomial(17, 1.0, 1) == 17.0
+    for n, p in ((40, 0.2), (100, 0.3), (1000, 0.011), (2000, 0.5), (30, 0.9), (10 ** 6, 0.4)):
+        D = 60000
+        xs = np.array([orc.binomial(n, p, 10 ** 6 + i, 0, 0) for i in range(D)])
+        sd = math.sqrt(n * p * (1 - p))
+        assert abs(xs.mean() - n * p) < 5 * sd / math.sqrt(D)
+        assert abs(xs.var() / (sd * sd) - 1.0) < 0.03
+        edges = np.floor(n * p + np.linspace(-3.5, 3.5, 15) * sd)
+        edges = np.unique(np.clip(edges, -1, n))
+        obs = np.histogram(xs, np.concatenate([[-1.5], edges + 0.5, [n + 0.5]]))[0]
+        cdf = np.concatenate([[0.0], stats.binom.cdf(edges, n, p), [1.0]])
+        exp = np.diff(cdf) * D
+        keep = exp > 5
+        chi = ((obs[keep] - exp[keep]) ** 2 / exp[keep]).sum()
+        assert stats.chi2.sf(chi, keep.sum() - 1) > 1e-4, (n, p, chi)
+
+
+def test_component_counts_are_multinomial(orc, plan, env):
+    """The selection table of a waypoint: running sums of Multinomial(N, weights) counts; retired
+    components get nothing; a mixture with nothing alive sends everything to component 0."""
+    cfg = orc.config(plan, env, K=4)
+    state = orc.gmm_advance(cfg, orc.gmm_initial_state(cfg), None)
+    w = np.array([0.1, 0.4, 0.0, 0.5])
+    state[:, 12] = w
+    state[2, 13] = 0.0
+    N, D = 100000, 3000
+    cum = np.array([orc.component_counts(4, state, 1000 + i, 7, N) for i in range(D)])
+    counts = np.diff(np.concatenate([np.zeros((D, 1)), cum], axis=1), axis=1)
+    assert np.all(cum[:, -1] == N) and np.all(counts >= 0) and np.all(counts[:, 2] == 0)
+    for k in (0, 1, 3):
+        sd = math.sqrt(N * w[k] * (1 - w[k]))
+        assert abs(counts[:, k].mean() - N * w[k]) < 5 * sd / math.sqrt(D)
+        assert abs(counts[:, k].std() / sd - 1.0) < 0.08
+    assert abs(np.corrcoef(counts[:, 1], counts[:, 3])[0, 1] + math.sqrt(0.4 * 0.5 / (0.6 * 0.5))) < 0.05
+    state[:, 12] = 0.0
+    state[:, 13] = 0.0
+    assert list(orc.component_counts(4, state, 5, 0, 77)) == [77.0] * 4

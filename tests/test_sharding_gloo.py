@@ -37,7 +37,7 @@ class OracleEngine:
             c = self.chain
             self.state = self.orc.gmm_advance(self.cfg, self.state, m, c["applied"][w - 1],
                                               c["Mdiag"][w - 1], c["z"][w - 1])
-        mom = self.orc.gmm_waypoint(self.cfg, self.seed, w, self.state, self.first, self.count)
+        mom = self.orc.gmm_waypoint(self.cfg, self.seed, w, self.state, self.first, self.count, n_total=self.N)
         self.moments(w).copy_(torch.from_numpy(mom.ravel()))
 
     def end(self):
