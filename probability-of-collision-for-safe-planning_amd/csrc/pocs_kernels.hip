@@ -110,45 +110,93 @@ __device__ __forceinline__ double load_wt(const double* p) {
 // (waypoint 0, and after the all-reduce when sharded).
 #define POCS_ADV_SCRATCH(K) ((K) * (2 * POCS_STATE_STRIDE + POCS_NMOM + POCS_PARAM_STRIDE) + POCS_CHAIN_STRIDE + \
                              (int)(sizeof(pocs_sensor) / sizeof(double)))
-__device__ __forceinline__ void advance_mixture(const pocs_gmm_launch& a, int K, int w, int r, int lane,
-                                                double* scratch) {
-  const int ss = K * POCS_STATE_STRIDE, ps = K * POCS_PARAM_STRIDE, NC = K * POCS_NMOM;
+struct adv_ptrs {
+  double *l_prev, *l_mom, *l_ch, *l_sen, *l_next, *l_par;
+  double *g_state, *g_param;
+  const double *g_prev, *g_mom, *g_ch, *g_sen;
+  int ss, ps, NC;
+};
+__device__ __forceinline__ adv_ptrs advance_ptrs(const pocs_gmm_launch& a, int K, int w, int r, double* scratch) {
+  adv_ptrs p;
   constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
-  double* l_prev = scratch;
-  double* l_mom = l_prev + ss;
-  double* l_ch = l_mom + NC;
-  double* l_sen = l_ch + POCS_CHAIN_STRIDE;
-  double* l_next = l_sen + SEN;
-  double* l_par = l_next + ss;
+  p.ss = K * POCS_STATE_STRIDE; p.ps = K * POCS_PARAM_STRIDE; p.NC = K * POCS_NMOM;
+  p.l_prev = scratch;
+  p.l_mom = p.l_prev + p.ss;
+  p.l_ch = p.l_mom + p.NC;
+  p.l_sen = p.l_ch + POCS_CHAIN_STRIDE;
+  p.l_next = p.l_sen + SEN;
+  p.l_par = p.l_next + p.ss;
   // run r of the batch: state/param [r][W][..], moments [W][R][..] (one all-reduce per waypoint
   // covers every run), chain [r][W-1][..]
-  double* g_state = a.state + (size_t)r * a.W * ss;
-  double* g_param = a.param + (size_t)r * a.W * ps;
-  const double* g_prev = g_state + (size_t)(w > 0 ? w - 1 : 0) * ss;
-  const double* g_mom = a.moments + ((size_t)(w > 0 ? w - 1 : 0) * a.nruns + r) * NC;
-  const double* g_ch = a.chain + ((size_t)r * (a.W > 1 ? a.W - 1 : 1) + (w > 0 ? w - 1 : 0)) * POCS_CHAIN_STRIDE;
-  const double* g_sen = reinterpret_cast<const double*>(a.sensor);
-  for (int j = lane; j < ss; j += 64) l_prev[j] = g_prev[j];
-  if (w > 0) for (int j = lane; j < NC; j += 64) l_mom[j] = g_mom[j];
-  for (int j = lane; j < POCS_CHAIN_STRIDE; j += 64) l_ch[j] = g_ch[j];
-  for (int j = lane; j < SEN; j += 64) l_sen[j] = g_sen[j];
+  p.g_state = a.state + (size_t)r * a.W * p.ss;
+  p.g_param = a.param + (size_t)r * a.W * p.ps;
+  p.g_prev = p.g_state + (size_t)(w > 0 ? w - 1 : 0) * p.ss;
+  p.g_mom = a.moments + ((size_t)(w > 0 ? w - 1 : 0) * a.nruns + r) * p.NC;
+  p.g_ch = a.chain + ((size_t)r * (a.W > 1 ? a.W - 1 : 1) + (w > 0 ? w - 1 : 0)) * POCS_CHAIN_STRIDE;
+  p.g_sen = reinterpret_cast<const double*>(a.sensor);
+  return p;
+}
+
+// first half: inputs -> LDS, one component per lane through truncation, EKF and Cholesky
+__device__ __forceinline__ void advance_components(const pocs_gmm_launch& a, int K, int w, int r, int lane, double* scratch) {
+  const adv_ptrs p = advance_ptrs(a, K, w, r, scratch);
+  constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
+  for (int j = lane; j < p.ss; j += 64) p.l_prev[j] = p.g_prev[j];
+  if (w > 0) for (int j = lane; j < p.NC; j += 64) p.l_mom[j] = p.g_mom[j];
+  for (int j = lane; j < POCS_CHAIN_STRIDE; j += 64) p.l_ch[j] = p.g_ch[j];
+  for (int j = lane; j < SEN; j += 64) p.l_sen[j] = p.g_sen[j];
   __threadfence_block();
   __builtin_amdgcn_wave_barrier();
   if (lane < K)
-    pocs_gmm_advance_component(lane, l_prev, (w == 0) ? nullptr : l_mom, l_ch, l_ch + 3, l_ch + POCS_CHAIN_Z,
-                               reinterpret_cast<const pocs_sensor*>(l_sen), l_next, l_par);
+    pocs_gmm_advance_component(lane, p.l_prev, (w == 0) ? nullptr : p.l_mom, p.l_ch, p.l_ch + 3, p.l_ch + POCS_CHAIN_Z,
+                               reinterpret_cast<const pocs_sensor*>(p.l_sen), p.l_next, p.l_par);
   __threadfence_block();
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) pocs_gmm_normalise(K, w > 0, l_next, l_par, a.hdr[r].seed, (uint32_t)w, (double)a.n_total);
+}
+
+// The component counts of waypoint w as they will come out unless a Cholesky factorisation fails
+// in advance_components (which nobody can know before it has run): one lane of ANOTHER wave draws
+// them while the EKF lanes work.  spec = K cumulative counts, then K alive flags assumed.
+#define POCS_SPEC_SCRATCH(K) ((K) * (POCS_STATE_STRIDE + 2))
+__device__ __forceinline__ void speculate_counts(const pocs_gmm_launch& a, int K, int w, int r, double* spec) {
+  const adv_ptrs p = advance_ptrs(a, K, w, r, nullptr);
+  double* st = spec + 2 * K;                                   // a K x STATE_STRIDE image: only [12], [13] matter
+  for (int k = 0; k < K; ++k) {
+    const double alive_prev = p.g_prev[k * POCS_STATE_STRIDE + 13];
+    const double n = p.g_mom[k * POCS_NMOM];
+    const bool alive = alive_prev != 0.0 && n >= 2.0;          // pocs_gmm_advance_component / pocs_truncated_moments
+    st[k * POCS_STATE_STRIDE + 12] = alive ? n : 0.0;
+    st[k * POCS_STATE_STRIDE + 13] = alive ? alive_prev : 0.0;
+    spec[K + k] = st[k * POCS_STATE_STRIDE + 13];
+  }
+  const int last_alive = pocs_normalise_weights(K, 1, st);
+  pocs_component_counts(K, st, last_alive, a.hdr[r].seed, (uint32_t)w, (double)a.n_total, spec, 1);
+}
+
+// second half: weights, component counts (the speculated ones if their premise held), write back
+__device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, int w, int r, int lane, double* scratch,
+                                               const double* spec) {
+  const adv_ptrs p = advance_ptrs(a, K, w, r, scratch);
+  if (lane == 0) {
+    bool use_spec = spec != nullptr;
+    if (use_spec) for (int k = 0; k < K; ++k) use_spec = use_spec && (p.l_next[k * POCS_STATE_STRIDE + 13] == spec[K + k]);
+    if (use_spec) {
+      (void)pocs_normalise_weights(K, 1, p.l_next);
+      for (int k = 0; k < K; ++k) p.l_par[k * POCS_PARAM_STRIDE + 9] = spec[k];
+    } else {
+      pocs_gmm_normalise(K, w > 0, p.l_next, p.l_par, a.hdr[r].seed, (uint32_t)w, (double)a.n_total);
+    }
+  }
   __threadfence_block();
   __builtin_amdgcn_wave_barrier();
-  for (int j = lane; j < ss; j += 64) g_state[(size_t)w * ss + j] = l_next[j];
-  for (int j = lane; j < ps; j += 64) g_param[(size_t)w * ps + j] = l_par[j];
+  for (int j = lane; j < p.ss; j += 64) p.g_state[(size_t)w * p.ss + j] = p.l_next[j];
+  for (int j = lane; j < p.ps; j += 64) p.g_param[(size_t)w * p.ps + j] = p.l_par[j];
 }
 
 __global__ __launch_bounds__(64) void k_gmm_advance(pocs_gmm_launch a, int K) {
   __shared__ double s_adv[POCS_ADV_SCRATCH(POCS_MAX_GAUSSIANS)];
-  advance_mixture(a, K, a.waypoint, blockIdx.x, threadIdx.x, s_adv);      // one block per run
+  advance_components(a, K, a.waypoint, blockIdx.x, threadIdx.x, s_adv);      // one block per run
+  advance_finish(a, K, a.waypoint, blockIdx.x, threadIdx.x, s_adv, nullptr);
 }
 
 #if defined(POCS_TRACE_PHASES)     // timing-only build (tools/fixed_cost.py): 100 MHz timestamps per phase
@@ -170,6 +218,7 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
   __shared__ double s_red[TB / 16][NC];     // one row of sums per 16-lane DPP row
   __shared__ double s_part[TB];
   __shared__ double s_adv[POCS_ADV_SCRATCH(K)];
+  __shared__ double s_spec[POCS_SPEC_SCRATCH(K)];
   __shared__ double s_keep[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];
   __shared__ pocs_tables s_tab;
   __shared__ int s_nkeep;
@@ -420,7 +469,10 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
     if (a.advance_in_tail) {
       __syncthreads();
       POCS_PHASE(8);
-      if (tid < 64) advance_mixture(a, K, w + 1, r, tid, s_adv);
+      if (tid < 64) advance_components(a, K, w + 1, r, tid, s_adv);
+      else if (tid == 64) speculate_counts(a, K, w + 1, r, s_spec);       // meanwhile, on another wave
+      __syncthreads();
+      if (tid < 64) advance_finish(a, K, w + 1, r, tid, s_adv, s_spec);
     }
     POCS_PHASE(9);
 #if defined(POCS_TRACE_PHASES)

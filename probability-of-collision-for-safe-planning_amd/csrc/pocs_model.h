@@ -314,8 +314,7 @@ POCS_HD void pocs_gmm_advance_component(int k, const double* prev, const double*
 // order (a retired component has weight 0 and gets none; if every component is retired,
 // component 0's frozen mean receives all samples): global sample i belongs to the first
 // component whose entry exceeds i.
-POCS_HD void pocs_gmm_normalise(int K, int renorm, double* next, double* param, uint64_t seed,
-                                uint32_t waypoint, double n_total) {
+POCS_HD int pocs_normalise_weights(int K, int renorm, double* next) {
   double wsum = 0.0;
   for (int k = 0; k < K; ++k) wsum += next[k * POCS_STATE_STRIDE + 12];
   // normalise(collisionCounts,1,1).row(1): divide by the L1 norm, a zero norm divides by 1.
@@ -326,6 +325,12 @@ POCS_HD void pocs_gmm_normalise(int K, int renorm, double* next, double* param, 
     if (renorm) o[12] = o[12] / den;
     if (o[13] != 0.0 && o[12] > 0.0) last_alive = k;
   }
+  return last_alive;
+}
+
+// Cumulative component counts from normalised weights (next[k][12]) and alive flags (next[k][13]).
+POCS_HD void pocs_component_counts(int K, const double* next, int last_alive, uint64_t seed,
+                                   uint32_t waypoint, double n_total, double* cum, int cum_stride) {
   double suffix[POCS_MAX_GAUSSIANS];
   double tail = 0.0;
   for (int k = K - 1; k >= 0; --k) {
@@ -347,6 +352,12 @@ POCS_HD void pocs_gmm_normalise(int K, int renorm, double* next, double* param, 
     }
     rem -= nk;
     run += nk;
-    param[k * POCS_PARAM_STRIDE + 9] = run;
+    cum[k * cum_stride] = run;
   }
+}
+
+POCS_HD void pocs_gmm_normalise(int K, int renorm, double* next, double* param, uint64_t seed,
+                                uint32_t waypoint, double n_total) {
+  const int last_alive = pocs_normalise_weights(K, renorm, next);
+  pocs_component_counts(K, next, last_alive, seed, waypoint, n_total, param + 9, POCS_PARAM_STRIDE);
 }
