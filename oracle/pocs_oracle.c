@@ -50,7 +50,7 @@
 #define ORC_STATE 16
 
 /* ------------------------------------------------------------------------------------------ */
-/* random streams (build spec "POCS numerics v5")                          */
+/* random streams (build spec "POCS numerics v6")                          */
 /* ------------------------------------------------------------------------------------------ */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};

@@ -21,7 +21,7 @@
 #include "../../include/pocs.h"
 #include "pocs_kernels.h"
 
-#define POCS_VERSION_STRING "pocs-mi355x 0.1 (gfx950; numerics v5)"
+#define POCS_VERSION_STRING "pocs-mi355x 0.1 (gfx950; numerics v6)"
 
 namespace {
 

@@ -6,7 +6,7 @@
 //     is an explicit fma();
 //   * only +, -, *, /, sqrt, fma, rint and integer ops are used (all correctly rounded on
 //     both sides), never a vendor libm transcendental.
-// The spec ("POCS numerics v5") is written out in DESIGN.md section 4; the CPU oracle under
+// The spec ("POCS numerics v6") is written out in DESIGN.md section 4; the CPU oracle under
 // oracle/ holds an independent plain-C restatement of the same spec and is never linked here.
 //
 // What this replaces in the reference: Armadillo's RNG + mvnrnd (GM_Model.h:83-116,
