@@ -67,6 +67,7 @@ POCS_HD bool pocs_box_hit(double px, double py, double sn, double cs, double rx,
 // checkCollision for one pose: true if the footprint touches any of the M obstacles.
 POCS_HD bool pocs_pose_collides(double x, double y, double th, const pocs_footprint* fp,
                                 const double* obs, int M, const pocs_tables* T) {
+  if (M <= 0) return false;                     // nothing in reach (k_gmm_step: every obstacle culled): no heading needed
   double sn, cs;
   pocs_sincos_tab(th, T, &sn, &cs);
   double px = x, py = y;
