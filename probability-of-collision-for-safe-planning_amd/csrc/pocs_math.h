@@ -263,10 +263,12 @@ POCS_HD void pocs_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint
   *spare = a.w;
 }
 
-// sqrt for 0 <= t <= 64 (the squared Box-Muller radius), correctly rounded like sqrt().  On the
+// sqrt for 0 < t <= 64 (the squared Box-Muller radius), correctly rounded like sqrt().  On the
 // device: the compiler's own f64 expansion (v_rsq_f64 seed, one coupled Goldschmidt step, two
 // residual corrections) without the 2^+-256 range scaling it wraps around it for arguments below
-// 2^-767, which cannot occur here; sqrt(+-0) = +-0 is selected explicitly (rsq(0) = inf).
+// 2^-767 and without its select for +-0 / inf: t = |-2 log u| is never 0 (the smallest value, at
+// u = 1, is the rounding error 4e-19 of the table log; every other word gives >= 4.6e-10 --
+// pinned by tests/test_product_host_vs_oracle.py) and never exceeds 44.4.
 POCS_HD double pocs_sqrt_radius2(double t) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const double y = __builtin_amdgcn_rsq(t);
@@ -279,7 +281,7 @@ POCS_HD double pocs_sqrt_radius2(double t) {
   g = fma(d, h, g);
   d = fma(-g, g, t);
   g = fma(d, h, g);
-  return (t == 0.0) ? t : g;
+  return g;
 #else
   return sqrt(t);
 #endif

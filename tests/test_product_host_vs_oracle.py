@@ -59,7 +59,8 @@ def test_table_functions_bitwise_and_accurate(hh, orc):
         # cancels, so its RELATIVE error there is larger than the polynomial form's -- harmless
         worst = max(worst, abs(got - want) / max(abs(want), 1.0))
     assert worst < 3e-16, worst
-    assert abs(hh.hh_log_unit32(2 ** 32 - 1)) < 2e-16            # u = 1: radius 0
+    assert 0.0 < abs(hh.hh_log_unit32(2 ** 32 - 1)) < 2e-16      # u = 1: radius ~0, but never exactly 0 (the device
+    assert all(abs(hh.hh_log_unit32(2 ** 32 - 1 - j)) > 2e-10 for j in range(1, 1000))    # sqrt sequence divides by it)
     assert math.sqrt(-2 * hh.hh_log_unit32(0)) < 6.661           # the bound the obstacle culling uses
     s, c = C.c_double(), C.c_double()
     for x in np.concatenate([rng.uniform(-20, 20, 8000), rng.uniform(-1e4, 1e4, 1000), [0.0, -0.0, 6.283185307179586, 1.5707963267948966]]):
