@@ -7,13 +7,12 @@
 #include "pocs_model.h"
 
 #define POCS_BLOCK 256        // MC kernels
-// k_gmm_step: ONE block per CU, as many waves as the register budget of the instantiation allows:
-// K = 1 needs <= 128 VGPRs -> 16 waves (four per SIMD), K <= 3 <= 170 -> 12 waves (three per SIMD),
-// K >= 4 holds 11 K accumulators -> 8 waves.
+// k_gmm_step: ONE block per CU of 768 threads = three waves per SIMD (<= 170 VGPRs; the kernel holds
+// one component's sums per thread whatever K is).
 #ifdef POCS_GMM_BLOCK                      // sweeps: force one size for every K
 #define POCS_GMM_BLOCK_OF(K) (POCS_GMM_BLOCK)
 #else
-#define POCS_GMM_BLOCK_OF(K) ((K) == 1 ? 1024 : (K) <= 3 ? 768 : 512)
+#define POCS_GMM_BLOCK_OF(K) ((K) == 1 ? 1024 : 768)      // K = 1 needs no component bookkeeping: 128 VGPRs, four waves
 #endif
 #define POCS_MAX_BLOCKS 2048
 // chain record (doubles), one per step i < W-1:

@@ -206,6 +206,27 @@ __device__ unsigned long long g_phase[64];
 #define POCS_PHASE(i) do { } while (0)
 #endif
 
+// A wave leaves component `k`: its 16-lane row sums of (nFree, nColl, 9 sums) are ADDED to the
+// block's LDS rows of that component (every wave owns its rows; a wave meets a component once,
+// the add only matters for a component it never touched: + 0) and the thread-private sums restart.
+template <int TB, int NC>
+__device__ __forceinline__ void flush_component(double (*s_red)[NC], int k, double (&acc)[9], unsigned& nfree,
+                                                unsigned& ncoll, int tid) {
+  const int row = tid >> 4;
+  const bool writer = (tid & 15) == 0;
+  const unsigned nf = row_sum_u32(nfree);
+  const unsigned nc = row_sum_u32(ncoll);
+  double* dst = &s_red[row][k * POCS_NMOM];
+  if (writer) { dst[0] += (double)nf; dst[1] += (double)nc; }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const double v = row_sum(acc[j]);
+    if (writer) dst[2 + j] += v;
+    acc[j] = 0.0;
+  }
+  nfree = 0u; ncoll = 0u;
+}
+
 template <int K, bool STORE, int TB>
 __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
 #if defined(POCS_TRACE_PHASES)
@@ -237,14 +258,15 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
     s_par[j] = a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j];
   const uint64_t seed = a.hdr[r].seed;
 
-  double acc[K][9];
-  unsigned nfree[K], ncoll[K];
+  // Samples come in component blocks and a thread's sample indices only grow, so a wave works
+  // through the components in order: ONE set of sums per thread (the wave's current component),
+  // folded into the block's LDS rows when the wave moves on to the next component.
+  double acc[9];
+  unsigned nfree = 0u, ncoll = 0u;
+  int kcur = 0;                                      // wave-uniform
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    nfree[k] = 0u; ncoll[k] = 0u;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) acc[k][j] = 0.0;
-  }
+  for (int j = 0; j < 9; ++j) acc[j] = 0.0;
+  for (int j = tid; j < (TB / 16) * NC; j += TB) (&s_red[0][0])[j] = 0.0;
   __syncthreads();
   POCS_PHASE(1);
 
@@ -303,7 +325,7 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
   int16_t* const fr = a.flags + (size_t)r * a.sample_stride;
   for (long long base = (long long)blockIdx.x * TB; base < npairs; base += stride) {
     const long long lp = base + tid;
-    if (lp >= npairs) continue;
+    const bool live = lp < npairs;                 // a lane past the end computes, masked: the row sums below need every lane
     double zz[2][3];
     uint32_t spare[2];
 #if defined(POCS_ABLATE_RNG)          // timing-only builds (tools/ablate.sh): outputs are wrong
@@ -323,7 +345,7 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
     pocs_normal3_pair(seed_it, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, &s_tab, zz[0], zz[1], &spare[0], &spare[1]);
 #endif
     const long long i0 = 2 * lp;
-    const bool two = (i0 + 1) < a.count;          // false only for the last sample of an odd shard
+    const bool two = live && (i0 + 1) < a.count;  // false only for the last sample of an odd shard
     const double gbase = first_d + (double)i0;     // global index of sample 2*lp (exact: < 2^53)
     double xs[2], ys[2], ts[2];
     bool hits[2];
@@ -349,40 +371,45 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
       xs[h] = x; ys[h] = y; ts[h] = t; hits[h] = hit; ks[h] = k;
     }
 #if defined(POCS_ABLATE_MOMENTS)
-    acc[0][0] += xs[0] + ys[0] + ts[0] + xs[1]; nfree[0] += hits[0] ? 0u : 1u; ncoll[0] += (two && ks[1] == 0) ? 1u : 0u;
+    acc[0] += xs[0] + ys[0] + ts[0] + xs[1]; nfree += hits[0] ? 0u : 1u; ncoll += (two && ks[1] == 0) ? 1u : 0u;
 #else
-    // T1 sums: acc_k += ind * (x, y, t, xx, xy, xt, yy, yt, tt) with ind = 1.0 for a collision-free
-    // sample of component k, else 0.0 (fma(1, v, acc) == acc + v, fma(0, v, acc) == acc exactly).
-    // Samples come in component blocks, so a wave sits in ONE component except where two blocks
-    // meet: then only that component's sums are touched, chosen by scalar compares; the general
-    // form (every component, per-lane indicator) serves the few waves that straddle a boundary.
+    // T1 sums: acc += ind * (x, y, t, xx, xy, xt, yy, yt, tt) with ind = 1.0 for a collision-free
+    // sample of the component being accumulated, else 0.0 (fma(1, v, acc) == acc + v, fma(0, v, acc)
+    // == acc exactly).  A wave sits in ONE component block except where two blocks meet; the
+    // components present in the wave are visited in increasing order (scalar loop), the previous
+    // component's sums being flushed to the LDS rows first.
     {
-      const int ku = __builtin_amdgcn_readfirstlane(ks[0]);
-      const bool uniform = __ballot(ks[0] != ku || ks[1] != ku) == 0ull;
+      // sample indices grow with the lane: lane 0 holds the wave's first component, lane 63 its last
+      const int klo = __builtin_amdgcn_readfirstlane(live ? ks[0] : K);
+      const int khi = (__ballot(live) == ~0ull) ? __builtin_amdgcn_readlane(ks[1], 63) : K - 1;
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
-        if (uniform ? (ku != kk) : false) continue;                  // scalar: skip the other components
+        if (kk < klo || kk > khi) continue;                                   // scalar compares
+        if (kk != kcur) {
+          flush_component<TB, NC>(s_red, kcur, acc, nfree, ncoll, tid);
+          kcur = kk;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const bool sel = ((h == 0) || two) && (uniform || ks[h] == kk);
+          const bool sel = (h == 0 ? live : two) && ks[h] == kk;
           const double x = xs[h], y = ys[h], t = ts[h];
-          nfree[kk] += (sel && !hits[h]) ? 1u : 0u;
-          ncoll[kk] += (sel && hits[h]) ? 1u : 0u;
+          nfree += (sel && !hits[h]) ? 1u : 0u;
+          ncoll += (sel && hits[h]) ? 1u : 0u;
           const double ind = (sel && !hits[h]) ? 1.0 : 0.0;
-          acc[kk][0] = fma(ind, x, acc[kk][0]);
-          acc[kk][1] = fma(ind, y, acc[kk][1]);
-          acc[kk][2] = fma(ind, t, acc[kk][2]);
-          acc[kk][3] = fma(ind, x * x, acc[kk][3]);
-          acc[kk][4] = fma(ind, x * y, acc[kk][4]);
-          acc[kk][5] = fma(ind, x * t, acc[kk][5]);
-          acc[kk][6] = fma(ind, y * y, acc[kk][6]);
-          acc[kk][7] = fma(ind, y * t, acc[kk][7]);
-          acc[kk][8] = fma(ind, t * t, acc[kk][8]);
+          acc[0] = fma(ind, x, acc[0]);
+          acc[1] = fma(ind, y, acc[1]);
+          acc[2] = fma(ind, t, acc[2]);
+          acc[3] = fma(ind, x * x, acc[3]);
+          acc[4] = fma(ind, x * y, acc[4]);
+          acc[5] = fma(ind, x * t, acc[5]);
+          acc[6] = fma(ind, y * y, acc[6]);
+          acc[7] = fma(ind, y * t, acc[7]);
+          acc[8] = fma(ind, t * t, acc[8]);
         }
       }
     }
 #endif
-    if (STORE) {
+    if (STORE && live) {
       // Both poses of the pair leave together.  For the last sample of an odd shard the second
       // slot is the pair's unused twin: it lands in the padding element of the run's slice
       // (sample_stride >= count + 1 then) and is never read back.  Written once, never re-read by
@@ -400,22 +427,8 @@ __global__ __launch_bounds__(TB) void k_gmm_step(pocs_gmm_launch a) {
 #if defined(POCS_TRACE_PHASES)
   if (threadIdx.x == 0 && blockIdx.y == 0) ph[11] = __builtin_readcyclecounter() - ph[10];
 #endif
-  // ---- tail: DPP row sums -> one LDS row per 16 lanes -> fixed-order sum over the TB/16 rows
-  {
-    const int row = tid >> 4;
-    const bool writer = (tid & 15) == 0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const unsigned nf = row_sum_u32(nfree[k]);
-      const unsigned nc = row_sum_u32(ncoll[k]);
-      if (writer) { s_red[row][k * POCS_NMOM] = (double)nf; s_red[row][k * POCS_NMOM + 1] = (double)nc; }
-#pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        const double v = row_sum(acc[k][j]);
-        if (writer) s_red[row][k * POCS_NMOM + 2 + j] = v;
-      }
-    }
-  }
+  // ---- tail: the last component's sums -> LDS rows; then a fixed-order sum over the TB/16 rows
+  flush_component<TB, NC>(s_red, kcur, acc, nfree, ncoll, tid);
   __syncthreads();
   POCS_PHASE(4);
   if (tid < NC) {
