@@ -7,12 +7,13 @@
 #include "pocs_model.h"
 
 #define POCS_BLOCK 256        // MC kernels
-// k_gmm_step: ONE block per CU of 768 threads = three waves per SIMD (<= 170 VGPRs; the kernel holds
-// one component's sums per thread whatever K is).
+// k_gmm_step: ONE block per CU.  The kernel holds one component's sums per thread whatever K is
+// (~149 VGPRs unconstrained).  1024 threads = four waves per SIMD at <= 128 VGPRs measured faster up
+// to K = 5 in spite of ~20 spilled registers (+3 %), 768 threads = three waves beyond (K = 8: +2 %).
 #ifdef POCS_GMM_BLOCK                      // sweeps: force one size for every K
 #define POCS_GMM_BLOCK_OF(K) (POCS_GMM_BLOCK)
 #else
-#define POCS_GMM_BLOCK_OF(K) ((K) == 1 ? 1024 : 768)      // K = 1 needs no component bookkeeping: 128 VGPRs, four waves
+#define POCS_GMM_BLOCK_OF(K) ((K) <= 5 ? 1024 : 768)
 #endif
 #define POCS_MAX_BLOCKS 2048
 // chain record (doubles), one per step i < W-1:
