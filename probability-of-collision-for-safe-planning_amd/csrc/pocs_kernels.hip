@@ -193,10 +193,14 @@ __device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, 
   for (int j = lane; j < p.ps; j += 64) p.g_param[(size_t)w * p.ps + j] = p.l_par[j];
 }
 
-__global__ __launch_bounds__(64) void k_gmm_advance(pocs_gmm_launch a, int K) {
+__global__ __launch_bounds__(128) void k_gmm_advance(pocs_gmm_launch a, int K) {
   __shared__ double s_adv[POCS_ADV_SCRATCH(POCS_MAX_GAUSSIANS)];
-  advance_components(a, K, a.waypoint, blockIdx.x, threadIdx.x, s_adv);      // one block per run
-  advance_finish(a, K, a.waypoint, blockIdx.x, threadIdx.x, s_adv, nullptr);
+  __shared__ double s_spec[POCS_SPEC_SCRATCH(POCS_MAX_GAUSSIANS)];
+  const int tid = threadIdx.x, w = a.waypoint, r = blockIdx.x;      // one block per run
+  if (tid < 64) advance_components(a, K, w, r, tid, s_adv);
+  else if (tid == 64 && w > 0) speculate_counts(a, K, w, r, s_spec);  // meanwhile, on the second wave
+  __syncthreads();
+  if (tid < 64) advance_finish(a, K, w, r, tid, s_adv, w > 0 ? s_spec : nullptr);
 }
 
 #if defined(POCS_TRACE_PHASES)     // timing-only build (tools/fixed_cost.py): 100 MHz timestamps per phase
@@ -687,7 +691,7 @@ hipError_t pocs_launch_copy(const void* src, void* dst, long long bytes, hipStre
 }
 
 hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_gmm_advance, dim3(a.nruns), dim3(64), 0, s, a, K);
+  hipLaunchKernelGGL(k_gmm_advance, dim3(a.nruns), dim3(128), 0, s, a, K);
   return hipGetLastError();
 }
 hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s) {
