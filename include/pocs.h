@@ -101,6 +101,12 @@ int pocs_set_stream(pocs_ctx* ctx, void* hip_stream);                 /* launch 
  * reduced) moments of w-1 into the mixture, then samples + collides + reduces this shard. */
 int pocs_gmm_begin(pocs_ctx* ctx);
 int pocs_gmm_step_local(pocs_ctx* ctx, int waypoint);
+/* The two halves of step_local, for a caller that interleaves two contexts on one GPU and wants
+ * the small advance launch to overlap the other context's sampling kernel: advance_local(w) builds
+ * the mixture of waypoint w from the reduced moments of w-1, sample_local(w) samples + collides +
+ * reduces; both on the context's stream, in this order. */
+int pocs_gmm_advance_local(pocs_ctx* ctx, int waypoint);
+int pocs_gmm_sample_local(pocs_ctx* ctx, int waypoint);
 void* pocs_gmm_moments_ptr(pocs_ctx* ctx, int waypoint);              /* device pointer, f64[moments_len] */
 int pocs_gmm_moments_len(const pocs_ctx* ctx);                       /* batch x 11 x K: one exchange covers every run of the batch */
 int pocs_gmm_bind_moments(pocs_ctx* ctx, void* device_ptr, long long len_doubles);  /* optional: keep the [W][batch][11K] moments in a caller-owned device buffer (e.g. a torch tensor handed to all_reduce); NULL unbinds */

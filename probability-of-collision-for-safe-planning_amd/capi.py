@@ -49,6 +49,8 @@ SIGNATURES = {
     "pocs_set_stream": (C.c_int, [_vp, _vp]),
     "pocs_gmm_begin": (C.c_int, [_vp]),
     "pocs_gmm_step_local": (C.c_int, [_vp, C.c_int]),
+    "pocs_gmm_advance_local": (C.c_int, [_vp, C.c_int]),
+    "pocs_gmm_sample_local": (C.c_int, [_vp, C.c_int]),
     "pocs_gmm_moments_ptr": (_vp, [_vp, C.c_int]),
     "pocs_gmm_moments_len": (C.c_int, [_vp]),
     "pocs_gmm_bind_moments": (C.c_int, [_vp, _vp, C.c_longlong]),
@@ -255,6 +257,12 @@ class Context:
 
     def gmm_step_local(self, w):
         self._chk(self.lib.pocs_gmm_step_local(self.h, w))
+
+    def gmm_advance_local(self, w):
+        self._chk(self.lib.pocs_gmm_advance_local(self.h, w))
+
+    def gmm_sample_local(self, w):
+        self._chk(self.lib.pocs_gmm_sample_local(self.h, w))
 
     def gmm_moments_ptr(self, w):
         return self.lib.pocs_gmm_moments_ptr(self.h, w)

@@ -107,6 +107,7 @@ struct pocs_ctx {
   std::vector<double> last_moments;      // W x K x 11
   long long last_gmm_count = 0, last_mc_count = 0;
   int last_gmm_wp = -1;
+  int last_gmm_adv = -1;                 // last waypoint whose mixture has been built (step API)
   bool gmm_open = false;
 };
 
@@ -1129,20 +1130,36 @@ int pocs_gmm_begin(pocs_ctx* c) {
   if (int r = enqueue_ticket_reset(c)) return r;
   c->gmm_open = true;
   c->last_gmm_wp = -1;
+  c->last_gmm_adv = -1;
   return POCS_OK;
 }
 
-int pocs_gmm_step_local(pocs_ctx* c, int w) {
+int pocs_gmm_advance_local(pocs_ctx* c, int w) {
   if (!c) return POCS_E_ARG;
-  if (!c->gmm_open) return fail(c, POCS_E_ORDER, "pocs_gmm_step_local before pocs_gmm_begin");
+  if (!c->gmm_open) return fail(c, POCS_E_ORDER, "pocs_gmm_advance_local before pocs_gmm_begin");
+  if (w != c->last_gmm_wp + 1 || w != c->last_gmm_adv + 1 || w >= c->W)
+    return fail(c, POCS_E_ORDER, "advance of waypoint %d out of sequence", w);
+  if (int r = enqueue_advance(c, w)) return r;        // folds the (reduced) moments of w-1
+  c->last_gmm_adv = w;
+  return POCS_OK;
+}
+
+int pocs_gmm_sample_local(pocs_ctx* c, int w) {
+  if (!c) return POCS_E_ARG;
+  if (!c->gmm_open) return fail(c, POCS_E_ORDER, "pocs_gmm_sample_local before pocs_gmm_begin");
   if (w != c->last_gmm_wp + 1 || w >= c->W) return fail(c, POCS_E_ORDER, "waypoint %d out of sequence", w);
+  if (w != c->last_gmm_adv) return fail(c, POCS_E_ORDER, "waypoint %d sampled before pocs_gmm_advance_local(%d)", w, w);
   long long first, count;
   if (int r = gmm_shard(c, &first, &count)) return r;
-  if (int r = enqueue_advance(c, w)) return r;        // folds the (reduced) moments of w-1
   if (int r = enqueue_step(c, grid_for(count, c->batch, c->K), first, count, w, false, c->opt_profile ? w : -1)) return r;
   c->last_gmm_wp = w;
   c->last_gmm_count = count;
   return POCS_OK;
+}
+
+int pocs_gmm_step_local(pocs_ctx* c, int w) {
+  if (int r = pocs_gmm_advance_local(c, w)) return r;
+  return pocs_gmm_sample_local(c, w);
 }
 
 void* pocs_gmm_moments_ptr(pocs_ctx* c, int w) {

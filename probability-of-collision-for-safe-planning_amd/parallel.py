@@ -47,16 +47,24 @@ def run_gmm_sharded(engine, dist=None):
 
 def run_gmm_pipelined(engines, dist):
     """Two (or more) engines, each with its own batch of runs and its own stream, advanced waypoint
-    by waypoint in turn: while one engine's moments are in the all-reduce (and its next launch
-    waits for them), the other engine's kernel has the GPU.  Collectives are issued from this one
-    thread in the same order on every rank.  Returns the list of per-engine probabilities."""
+    by waypoint in turn: while one engine's moments are in the all-reduce (and its small mixture
+    advance runs), the other engine's sampling kernel has the GPU.  The sampling kernels alternate
+    strictly -- each waits for the previous engine's sampling kernel, an event, before it starts --
+    because two of them in flight would share the CUs block by block and reach their tails
+    together.  Collectives are issued from this one thread in the same order on every rank.
+    Returns the list of per-engine probabilities."""
     for e in engines:
         with e.stream_ctx():
             e.begin()
+    prev = None                                      # "the previous sampling kernel has finished"
     for w in range(engines[0].W):
         for e in engines:
             with e.stream_ctx():
-                e.step_local(w)
+                e.advance(w)                         # overlaps the other engine's sampling kernel
+                if prev is not None and len(engines) > 1:
+                    e.wait_event(prev)
+                e.sample(w)
+                prev = e.record_event()
                 if dist is not None:
                     dist.all_reduce(e.moments(w))
     out = []
@@ -112,6 +120,20 @@ class GpuEngine:
 
     def step_local(self, w):
         self.ctx.gmm_step_local(w)
+
+    def advance(self, w):
+        self.ctx.gmm_advance_local(w)
+
+    def sample(self, w):
+        self.ctx.gmm_sample_local(w)
+
+    def record_event(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream())
+        return ev
+
+    def wait_event(self, ev):
+        self.torch.cuda.current_stream().wait_event(ev)
 
     def moments(self, w):
         n = self.batch * self.K * 11           # one exchange per waypoint covers every run of the batch

@@ -31,14 +31,26 @@ class OracleEngine:
         n = self.K * 11
         return self.buf[w * n:(w + 1) * n]
 
-    def step_local(self, w):
+    def advance(self, w):
         if w > 0:                              # fold the (already reduced) moments of w-1
             m = self.moments(w - 1).numpy().reshape(self.K, 11)
             c = self.chain
             self.state = self.orc.gmm_advance(self.cfg, self.state, m, c["applied"][w - 1],
                                               c["Mdiag"][w - 1], c["z"][w - 1])
+
+    def sample(self, w):
         mom = self.orc.gmm_waypoint(self.cfg, self.seed, w, self.state, self.first, self.count, n_total=self.N)
         self.moments(w).copy_(torch.from_numpy(mom.ravel()))
+
+    def step_local(self, w):
+        self.advance(w)
+        self.sample(w)
+
+    def record_event(self):
+        return None
+
+    def wait_event(self, ev):
+        pass
 
     def end(self):
         from importlib import import_module
