@@ -152,6 +152,8 @@ class Context:
     def set_env(self, env):
         fp = env["footprint"]
         self._chk(self.lib.pocs_set_footprint(self.h, fp[0], fp[1], fp[2], fp[3]))
+        if env.get("boxes") is None:        # footprint only: the world itself is left as it is
+            return
         b = _arr(env["boxes"]).reshape(-1, 5)
         self._chk(self.lib.pocs_set_obstacles(self.h, b.ctypes.data_as(_dp), b.shape[0]))
 

@@ -56,6 +56,7 @@ struct pocs_ctx {
   uint64_t run_index = 0;
   pocs_footprint fp = {0.0, 0.0, 0.334, 0.334};
   std::vector<double> boxes;             // M x 5
+  bool have_obstacles = false;           // pocs_set_obstacles / addObstacle / clearObstacles was called at least once
   long long shard_first = -1, shard_count = -1;
   long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0;
   unsigned long long epoch = 0;          // bumped by every setter; part of the graph cache key
@@ -131,20 +132,27 @@ int fail(pocs_ctx* c, int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                    \
   } while (0)
 
-int ensure(pocs_ctx* c, DevBuf& b, size_t bytes) {
-  if (bytes == 0) bytes = 16;
-  if (b.cap >= bytes) return POCS_OK;
-  if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
-  HIPCHK(c, hipMalloc(&b.p, bytes));
-  b.cap = bytes;
-  return POCS_OK;
-}
-
 void drop_graphs(pocs_ctx* c) {
   if (c->graph_gmm) { hipGraphExecDestroy(c->graph_gmm); c->graph_gmm = nullptr; }
   if (c->graph_mc) { hipGraphExecDestroy(c->graph_mc); c->graph_mc = nullptr; }
   c->graph_gmm_key.clear();
   c->graph_mc_key.clear();
+}
+
+// Grow a device buffer.  The captured graphs bake device pointers in (d_hdr and d_chain are shared
+// by the GMM and the MC graph), so replacing ANY buffer drops both of them: the next run captures
+// again against the new pointers.
+int ensure(pocs_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (b.cap >= bytes) return POCS_OK;
+  if (b.p) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // nothing queued may still use the old buffer
+    drop_graphs(c);
+    HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0;
+  }
+  HIPCHK(c, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return POCS_OK;
 }
 
 int grid_blocks(long long count, int block, int default_bpc) {
@@ -298,6 +306,11 @@ int check_common(pocs_ctx* c) {
   if (!c->have_cov0) return fail(c, POCS_E_STATE, "setInitialCovariance missing");
   if (!c->have_traj || !c->have_odom) return fail(c, POCS_E_STATE, "setTrajectory / setOdometry missing");
   if (c->W < 1) return fail(c, POCS_E_STATE, "setPathLength missing");
+  // The reference receives its collision world through the module constructor (sim(penv),
+  // mcsimplugin.cpp:12 -> MCSimulator.h:139-156).  A context that was never given one would answer
+  // 0.0 for every run: refuse instead.  An explicitly empty world (clearObstacles) is allowed.
+  if (!c->have_obstacles)
+    return fail(c, POCS_E_STATE, "no collision world: pocs_set_obstacles / addObstacle / clearObstacles missing");
   return POCS_OK;
 }
 
@@ -870,6 +883,7 @@ int pocs_set_obstacles(pocs_ctx* c, const double* boxes, int M) {
     if (!(boxes[5 * m + 2] > 0) || !(boxes[5 * m + 3] > 0))
       return fail(c, POCS_E_ARG, "obstacle %d: half extents must be > 0", m);
   c->boxes.assign(boxes, boxes + (size_t)M * 5);
+  c->have_obstacles = true;
   c->env_dirty = true;
   return POCS_OK;
 }

@@ -26,6 +26,7 @@ def list2string(values):
 
 def push_configuration(mod, plan, env, params, num_particles, simoption, num_gaussians):
     """MCSimulation.py:154-207, command for command."""
+    mod.SendCommand("clearObstacles")            # the world description starts from an explicit (empty) table
     for b in np.asarray(env["boxes"]).reshape(-1, 5):
         mod.SendCommand("addObstacle " + list2string(repr(float(v)) for v in b))
     mod.SendCommand("setFootprint " + list2string(repr(float(v)) for v in env["footprint"]))

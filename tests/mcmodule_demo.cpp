@@ -26,6 +26,7 @@ int main(int argc, char** argv) {
     pocs::MCModule mod(0);
     std::ostringstream help; std::istringstream hi("help");
     mod.SendCommand(help, hi);
+    mod.SendCommand("clearObstacles");
     while (std::getline(ef, line)) {
       std::istringstream is(line); std::string kind; is >> kind;
       std::string rest; std::getline(is, rest);

@@ -435,6 +435,16 @@ def test_error_behaviour(pocs, plan, env):
         with pytest.raises(pocs.PocsError) as e:
             c.SendCommand("noSuchCommand 1")
         assert e.value.code == -5
+        # everything configured except the collision world: the reference gets its scene through the
+        # module constructor (mcsimplugin.cpp:12); a context that never got one must not answer 0.0
+        c.configure(plan, dict(footprint=env["footprint"], boxes=None), K=3, N=100, seed=1)
+        for cmd in ("runGMMEstimation", "runSimulation"):
+            with pytest.raises(pocs.PocsError) as e:
+                c.SendCommand(cmd)
+            assert e.value.code == -3 and "collision world" in str(e.value)
+        c.SendCommand("clearObstacles")                           # an explicitly empty world is a world
+        assert float(c.SendCommand("runGMMEstimation")) == 0.0
+        assert float(c.SendCommand("runSimulation")) == 0.0
         with pytest.raises(pocs.PocsError) as e:
             c.SendCommand("setNumGaussians 9")
         assert e.value.code == -1
@@ -444,6 +454,27 @@ def test_error_behaviour(pocs, plan, env):
         assert c.SendCommand("ArmaCommand") == ""
     finally:
         c.close()
+
+
+def test_graphs_survive_buffer_growth(pocs, orc, plan, env):
+    """A captured launch graph bakes device pointers in.  MC at batch 1 captures graph_mc; a GMM call
+    with run-ahead 16 then grows the shared header / chain buffers (freed and reallocated); the next
+    MC call must not replay the stale graph: counters bit-exact against the oracle before and after."""
+    N = 3000
+    cfg = orc.config(plan, env, K=3)
+    with pocs.Context(0) as c:
+        c.configure(plan, env, K=3, N=N, seed=77)
+        n0 = c.mc_run_local()
+        assert n0 == orc.run_mc(cfg, 77, N)[0]
+        c.set_option(pocs.OPT_RUN_AHEAD, 16)
+        c.set_seed(77)
+        p = c.run_gmm_estimation()                              # R = 16: d_hdr / d_chain are replaced
+        assert abs(p - orc.run_gmm(cfg, 77, N)["prob"]) <= 2.0 / N
+        c.set_option(pocs.OPT_RUN_AHEAD, 1)
+        c.set_seed(77)
+        assert c.mc_run_local() == n0
+        _, hits = c.particles(N)
+        assert np.array_equal(hits, orc.run_mc(cfg, 77, N)[1])
 
 
 def test_rotated_obstacles_and_offset_footprint(ctx, orc, plan):
