@@ -48,6 +48,41 @@ def test_mc_hits_bit_exact(ctx, orc, plan, env, N):
     assert p == n / N
 
 
+def test_cfg5_mc_rollouts_full_size(ctx, pocs, orc, plan, env):
+    """BASELINE.json configs[4] at full size: 10^5 roll-outs x 500 waypoints (per-particle footprint
+    check at every waypoint).  Hit counters and final particles bit for bit against the oracle
+    (~5 s of CPU), for the streaming kernels and the in-register variant."""
+    big = pocs.resample_plan(plan, 500)
+    N = 100_000
+    cfg = orc.config(big, env, K=1)
+    n, hits, parts = orc.run_mc(cfg, SEED, N, want_particles=True)
+    for fused in (0, 1):
+        ctx.configure(big, env, K=1, N=N, seed=SEED)
+        ctx.set_option(pocs.OPT_MC_FUSED, fused)
+        p = ctx.run_simulation()
+        xyz, got_hits = ctx.particles(N)
+        ctx.set_option(pocs.OPT_MC_FUSED, 0)
+        assert p == n / N
+        assert np.array_equal(got_hits, hits) and np.array_equal(xyz, parts)
+    assert hits.max() > 50 and 0 < n < N                       # a roll-out that stays in collision for many waypoints
+
+
+def test_cfg1_exact_shape(ctx, orc, plan, env):
+    """BASELINE.json configs[0] exactly: bundled plan, 1k particles, K = 3 -- every stage against the
+    oracle (this is the shape at which components get close to running out of survivors)."""
+    cfg = orc.config(plan, env, K=3)
+    for seed in (SEED, SEED + 1, SEED + 2):
+        ctx.configure(plan, env, K=3, N=1000, seed=seed)
+        p = ctx.run_gmm_estimation()
+        want = orc.run_gmm(cfg, seed, 1000, want_samples=True)
+        got_m = np.array([ctx.moments(w, 3) for w in range(56)])
+        assert np.array_equal(got_m[..., :2], want["moments"][..., :2])
+        assert np.array_equal(ctx.waypoint_probabilities(), want["probs"]) and abs(p - want["prob"]) < 1e-12
+        assert np.array_equal(ctx.gmm_samples(1000)[1], want["flags"])
+        ctx.set_seed(seed)
+        assert ctx.run_simulation() == orc.run_mc(cfg, seed, 1000)[0] / 1000
+
+
 def test_mc_fused_equals_streaming(ctx, pocs, plan, env):
     ctx.configure(plan, env, K=3, N=5000, seed=7)
     p1 = ctx.run_simulation()
