@@ -151,6 +151,15 @@ class Oracle:
         ok = self.lib.orc_chol3_lower(_p(S), _p(L))
         return ok, L
 
+    def mvnrnd_tape(self, mean, cov, z):
+        """mvnrnd on a given tape of normals; z and the result are n x 3 (rows = columns of the 3 x n matrix)."""
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        out = np.zeros_like(z)
+        ok = self.lib.orc_mvnrnd_tape(_p(np.ascontiguousarray(mean, dtype=np.float64)),
+                                      _p(np.ascontiguousarray(cov, dtype=np.float64).ravel()), _p(z),
+                                      C.c_longlong(z.shape[0]), _p(out))
+        return out if ok else None
+
     def cov_mean(self, rows):
         rows = np.ascontiguousarray(rows, np.float64)
         m, c = np.zeros(3), np.zeros(9)

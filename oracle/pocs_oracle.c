@@ -489,6 +489,24 @@ int orc_chol3_lower(const double C[9], double L[6]) {
   return 1;
 }
 
+/* mvnrnd(M, C, n) on a GIVEN tape of standard normals (glue_mvnrnd_meat.hpp:134-145: out = D * randn(3, n),
+ * each column += M, D = chol(C, "lower")).  z / out: 3 x n column-major.  The same three fma chains
+ * orc_gmm_waypoint applies to its own draws; exists so that the transform can be compared with the
+ * reference's mvnrnd run on the same tape (tests/test_oracle_vs_ref_lapack.py).  Returns 0 when the
+ * factorisation fails (the reference then takes its eigen-decomposition path, :100-132). */
+int orc_mvnrnd_tape(const double mean[3], const double C[9], const double* z, long long n, double* out) {
+  double L[6];
+  if (!orc_chol3_lower(C, L)) return 0;
+  for (long long i = 0; i < n; ++i) {
+    const double* zz = z + 3 * i;
+    double* pt = out + 3 * i;
+    pt[0] = fma(L[0], zz[0], mean[0]);
+    pt[1] = fma(L[2], zz[1], fma(L[1], zz[0], mean[1]));
+    pt[2] = fma(L[5], zz[2], fma(L[4], zz[1], fma(L[3], zz[0], mean[2])));
+  }
+  return 1;
+}
+
 /* arma::mean(X,1) and arma::cov(X.t()) for X = 3 x n given as n rows of 3 (op_mean_meat.hpp:104-133,
  * op_cov_meat.hpp:26-53): acc = sum(A); out = A^T A; out -= acc^T acc / N; out /= (N-1). */
 void orc_cov_mean(const double* rows, long long n, double mean[3], double cov[9]) {
