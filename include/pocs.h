@@ -77,6 +77,10 @@ int pocs_send_command(pocs_ctx* ctx, const char* line, char* out, size_t cap);
                                       reference driver's one-command-per-run loop (MCSimulation.py:238-256) at batch throughput.
                                       Same runs, same seeds, same results and getters as one launch per run; any setter ends the
                                       serving and the run counter resumes after the last run handed out.  Text: setRunAhead R */
+#define POCS_OPT_PERSISTENT 6      /* 1 (default): a call that advances >= 16 runs (batch or run-ahead) is ONE launch for all W
+                                      waypoints of all of them (k_gmm_run: tasks from a queue, per-run `ready` words instead of
+                                      launch boundaries); fewer runs, or 0: one launch per waypoint (k_gmm_step + in-tail
+                                      mixture advance).  Same tasks, same arithmetic, bitwise the same results. */
 int pocs_set_option(pocs_ctx* ctx, int option, long long value);
 
 /* ---- batches of independent runs (ours) --------------------------------------------------

@@ -58,7 +58,7 @@ struct pocs_ctx {
   std::vector<double> boxes;             // M x 5
   bool have_obstacles = false;           // pocs_set_obstacles / addObstacle / clearObstacles was called at least once
   long long shard_first = -1, shard_count = -1;
-  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0;
+  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0, opt_persistent = 1;
   unsigned long long epoch = 0;          // bumped by every setter; part of the graph cache key
   int batch = 1;                         // independent GMM estimations advanced in lockstep per call
   // run-ahead (POCS_OPT_RUN_AHEAD): with batch == 1 a run* call evaluates the next `run_ahead` runs
@@ -171,35 +171,38 @@ int grid_blocks(long long count, int block, int default_bpc) {
   if (nb > POCS_MAX_BLOCKS) nb = POCS_MAX_BLOCKS;
   return (int)nb;
 }
-// k_gmm_step: blocks PER RUN.  One run alone takes one block per CU (256 partial rows); a batch of
-// R runs shares the chip, so each run gets ~target/R blocks (fewer, fatter blocks: head, tail and
-// partial rows are amortised over more samples).  POCS_GRID_TARGET overrides the total for sweeps.
-int grid_for(long long count, int runs, int K) {
-  static int target = -1, forced_per = -1;
-  if (target < 0) {
-    const char* e = getenv("POCS_GRID_TARGET");
-    target = e ? atoi(e) : 0;
-    if (target < 0 || target > 8192) target = 0;
-    const char* f = getenv("POCS_BLOCKS_PER_RUN");            // sweeps
-    forced_per = f ? atoi(f) : 0;
-    if (forced_per < 0 || forced_per > 256) forced_per = 0;
+// Task geometry of the GMM kernels (pocs_kernels.h): a chunk = one block iteration = TB pairs of
+// samples; a run's `chunks` are cut into `slices` contiguous ranges; task (w, r, j) = slice j of run r
+// at waypoint w.  Tasks per waypoint = runs x slices ~ 1.5 x the blocks resident on the chip, so that
+// a block leaving a task finds another one ready while the closing block of a run reduces and
+// advances its mixture (k_gmm_run), and a one-waypoint launch (k_gmm_step) fills the chip about evenly.
+// One run alone: as many slices as resident blocks.  POCS_SLICES overrides for sweeps.
+struct GmmGeometry { long long chunks; int slices; int blocks; };
+GmmGeometry gmm_geometry(long long count, int runs, int K) {
+  static int forced = -1, forced_blocks = -1;
+  if (forced < 0) {
+    const char* e = getenv("POCS_SLICES");
+    forced = e ? atoi(e) : 0;
+    if (forced < 0 || forced > 4096) forced = 0;
+    const char* b = getenv("POCS_RUN_BLOCKS");                 // sweeps: resident blocks of k_gmm_run
+    forced_blocks = b ? atoi(b) : 0;
+    if (forced_blocks < 0 || forced_blocks > 4096) forced_blocks = 0;
   }
-  const int one = grid_blocks(count, POCS_GMM_BLOCK_OF(K), 1);
-  if (runs <= 1) return one;
-  if (forced_per) return forced_per < one ? forced_per : one;
-  if (target) { const int per = target / runs > 0 ? target / runs : 1; return per < one ? per : one; }
-  // A block occupies a CU by itself, so R * per blocks run in ceil(R * per / 256) rounds, each as
-  // long as one block: a run's samples / per, plus the block's fixed head and tail (~5 us against
-  // ~2.5 ms of one CU for 10^6 samples).  Take the cheapest `per`; ties go to fewer blocks.
-  const double t_run = 2560.0 * (double)count * 1e-6, t_fixed = 5.0;
-  int best = 1;
-  double best_cost = 1e300;
-  for (int per = 1; per <= one && per <= 256; ++per) {
-    const double rounds = (double)(((long long)runs * per + 255) / 256);
-    const double cost = rounds * (t_run / per + t_fixed);
-    if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = per; }
-  }
-  return best;
+  const int tb = POCS_GMM_BLOCK_OF(K);
+  const long long npairs = (count + 1) / 2;
+  GmmGeometry g;
+  g.chunks = (npairs + tb - 1) / tb;
+  if (g.chunks < 1) g.chunks = 1;
+  const int resident = POCS_NUM_CUS * POCS_GMM_BLOCKS_PER_CU;
+  long long want = runs <= 1 ? resident : (3LL * resident / 2 + runs - 1) / runs;
+  if (forced) want = forced;
+  if (want < 1) want = 1;
+  if (want > g.chunks) want = g.chunks;
+  g.slices = (int)want;
+  const long long tasks = (long long)runs * g.slices;
+  g.blocks = (int)(tasks < resident ? tasks : resident);
+  if (forced_blocks) g.blocks = forced_blocks;
+  return g;
 }
 int grid_for_mc(long long count, int runs = 1) {                                      // MC kernels, per run
   // six 256-thread blocks per CU (69 VGPRs: plenty of room) keep enough loads in flight for the
@@ -417,6 +420,15 @@ int gmm_shard(pocs_ctx* c, long long* first, long long* count) {
   return POCS_OK;
 }
 
+// The synchronisation words of one call (pocs_kernels.h): [0] queue head, [1] give-up code, [2..3] pad,
+// [4 .. 4+Rpad) ready[r], then the tickets [R][W]; a block of its own, a multiple of 16 bytes, zeroed
+// by ONE memset node at the head of every call.
+size_t sync_ticket_offset(const pocs_ctx* c) { return POCS_SYNC_READY + (((size_t)c->batch + 3) & ~(size_t)3); }
+size_t sync_words(const pocs_ctx* c) {
+  const size_t n = sync_ticket_offset(c) + (size_t)c->batch * (size_t)(c->W > 0 ? c->W : 1);
+  return (n + 3) & ~(size_t)3;
+}
+
 long long sample_stride_of(long long count) { return count > 0 ? ((count + 1) & ~1LL) : 2; }   // even
 
 int gmm_prepare(pocs_ctx* c) {
@@ -427,7 +439,7 @@ int gmm_prepare(pocs_ctx* c) {
   if (int r = gmm_shard(c, &first, &count)) return r;
   if (int r = upload_static(c)) return r;
   const size_t W = (size_t)c->W, K = (size_t)c->K, R = (size_t)c->batch;
-  const int nblk = grid_for(count, c->batch, c->K);
+  const GmmGeometry geo = gmm_geometry(count, c->batch, c->K);
   if (int r = ensure(c, c->d_hdr, R * sizeof(pocs_run_header))) return r;
   if (int r = ensure(c, c->d_chain, R * (W > 1 ? W - 1 : 1) * POCS_CHAIN_STRIDE * sizeof(double))) return r;
   if (int r = ensure(c, c->d_state, R * W * K * POCS_STATE_STRIDE * sizeof(double))) return r;
@@ -436,8 +448,8 @@ int gmm_prepare(pocs_ctx* c) {
     if (int r = ensure(c, c->d_moments, W * R * K * POCS_NMOM * sizeof(double))) return r;
   if (c->ext_moments && c->ext_moments_len < (long long)(W * R * K * POCS_NMOM))
     return fail(c, POCS_E_BUFFER, "bound moments buffer too small");
-  if (int r = ensure(c, c->d_partial, R * (size_t)nblk * K * POCS_NMOM * sizeof(double))) return r;
-  if (int r = ensure(c, c->d_ticket, R * W * sizeof(unsigned))) return r;
+  if (int r = ensure(c, c->d_partial, R * (size_t)geo.slices * K * POCS_NMOM * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_ticket, sync_words(c) * sizeof(unsigned))) return r;
   if (c->opt_store) {
     const size_t n = R * (size_t)sample_stride_of(count);
     if (int r = ensure(c, c->d_sx, n * sizeof(double))) return r;
@@ -535,7 +547,10 @@ void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long
   a->param = (double*)c->d_param.p;
   a->moments = moments_dev(c);
   a->partial = (double*)c->d_partial.p;
-  a->ticket = (unsigned*)c->d_ticket.p;
+  a->sync = (unsigned*)c->d_ticket.p;
+  a->ticket = a->sync + sync_ticket_offset(c);
+  const GmmGeometry geo = gmm_geometry(count, c->batch, c->K);
+  a->slices = geo.slices; a->chunks = geo.chunks;
   a->x = (double*)c->d_sx.p; a->y = (double*)c->d_sy.p; a->th = (double*)c->d_st.p;
   a->flags = (int16_t*)c->d_flags.p;
   a->first = first; a->count = count; a->n_total = c->num_gmm;
@@ -554,31 +569,60 @@ int enqueue_advance(pocs_ctx* c, int w) {
   return POCS_OK;
 }
 
-int enqueue_step(pocs_ctx* c, int nblk, long long first, long long count, int w, bool advance_in_tail,
-                 int prof_slot) {
+int enqueue_step(pocs_ctx* c, long long first, long long count, int w, bool advance_in_tail, int prof_slot) {
   pocs_gmm_launch a;
   fill_gmm_launch(c, &a, first, count, w);
   a.advance_in_tail = (advance_in_tail && w + 1 < c->W) ? 1 : 0;
   if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot], c->stream));
-  HIPCHK(c, pocs_launch_gmm_step(c->K, nblk, a, c->stream));
+  HIPCHK(c, pocs_launch_gmm_step(c->K, a, c->stream));
   if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot + 1], c->stream));
   return POCS_OK;
 }
 
 int enqueue_ticket_reset(pocs_ctx* c) {
-  HIPCHK(c, hipMemsetAsync(c->d_ticket.p, 0, (size_t)c->batch * c->W * sizeof(unsigned), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_ticket.p, 0, sync_words(c) * sizeof(unsigned), c->stream));
   return POCS_OK;
 }
 
+// k_gmm_run or one k_gmm_step per waypoint?  The queue-driven kernel needs enough independent runs in
+// flight to cover the ~30 us in which the closing block of a run reduces and advances its mixture:
+// measured on MI355X (10^6 samples, K = 3) it wins from about 16 runs per call (20 runs: 1.06 vs
+// 0.98 x 10^11 evals/s; 64: equal) and loses below (8 runs: 0.67 vs 0.89; 1 run: 0.15 vs 0.34).
+// POCS_OPT_PERSISTENT = 0 forces the per-waypoint form, POCS_PERSISTENT_MIN_RUNS moves the threshold.
+bool use_persistent(const pocs_ctx* c) {
+  static int min_runs = -1;
+  if (min_runs < 0) {
+    const char* e = getenv("POCS_PERSISTENT_MIN_RUNS");
+    min_runs = e ? atoi(e) : 16;
+    if (min_runs < 1) min_runs = 1;
+  }
+  return c->opt_persistent && c->batch >= min_runs;
+}
+// How many launches of the hot kernel one whole-run call makes (what POCS_OPT_PROFILE brackets).
+size_t gmm_hot_launches(const pocs_ctx* c) { return use_persistent(c) ? 1 : (size_t)c->W; }
+
 int enqueue_gmm_all(pocs_ctx* c, long long first, long long count, bool prof) {
-  const int W = c->W, nblk = grid_for(count, c->batch, c->K);
+  const int W = c->W;
   if (int r = enqueue_ticket_reset(c)) return r;
   if (int r = enqueue_advance(c, 0)) return r;
-  for (int w = 0; w < W; ++w)
-    if (int r = enqueue_step(c, nblk, first, count, w, true, prof ? w : -1)) return r;
+  if (use_persistent(c)) {
+    // the whole run in ONE launch (k_gmm_run): tasks from a queue, the waypoint dependency of a run
+    // carried by its `ready` word
+    pocs_gmm_launch a;
+    fill_gmm_launch(c, &a, first, count, 0);
+    if (prof) HIPCHK(c, hipEventRecord(c->events[0], c->stream));
+    HIPCHK(c, pocs_launch_gmm_run(c->K, gmm_geometry(count, c->batch, c->K).blocks, a, c->stream));
+    if (prof) HIPCHK(c, hipEventRecord(c->events[1], c->stream));
+  } else {
+    for (int w = 0; w < W; ++w)
+      if (int r = enqueue_step(c, first, count, w, true, prof ? w : -1)) return r;
+  }
   const PinLayout pl = pin_layout(c);
   HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.moments, moments_dev(c),
                            (size_t)W * c->batch * c->K * POCS_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  // the call's give-up word travels back with the results
+  HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.total + c->batch + 1, (unsigned*)c->d_ticket.p + POCS_SYNC_ABORT,
+                           sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   return POCS_OK;
 }
 
@@ -620,9 +664,9 @@ void gmm_combine(pocs_ctx* c, const double* moments, double* probability) {
 
 std::string config_key(const pocs_ctx* c, long long first, long long count, const char* tag) {
   char buf[256];
-  snprintf(buf, sizeof buf, "%s e%llu W%d K%d R%d n%lld f%lld c%lld s%lld fu%lld st%p em%p", tag, c->epoch,
-           c->W, c->K, c->batch, c->num_gmm, first, count, c->opt_store, c->opt_fused, (void*)c->stream,
-           (void*)c->ext_moments);
+  snprintf(buf, sizeof buf, "%s e%llu W%d K%d R%d n%lld f%lld c%lld s%lld fu%lld pe%lld st%p em%p", tag, c->epoch,
+           c->W, c->K, c->batch, c->num_gmm, first, count, c->opt_store, c->opt_fused, c->opt_persistent,
+           (void*)c->stream, (void*)c->ext_moments);
   return buf;
 }
 
@@ -633,7 +677,7 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
   if (int r = gmm_shard(c, &first, &count)) return r;
   if (int r = gmm_upload_run(c)) return r;
   const bool prof = c->opt_profile != 0;
-  if (int r = prof_begin(c, (size_t)c->W)) return r;
+  if (int r = prof_begin(c, gmm_hot_launches(c))) return r;
   if (c->opt_graph && !prof) {
     const std::string key = config_key(c, first, count, "gmm");
     if (!c->graph_gmm || key != c->graph_gmm_key) {
@@ -655,7 +699,12 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
   }
   prefetch_next_batch(c);          // host chains of the next batch, while the GPU works on this one
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (int r = prof_collect(c, (size_t)c->W)) return r;
+  if (int r = prof_collect(c, gmm_hot_launches(c))) return r;
+  {
+    unsigned gave_up = 0;
+    memcpy(&gave_up, (double*)c->h_pin + pin_layout(c).total + c->batch + 1, sizeof gave_up);
+    if (gave_up) return fail(c, POCS_E_DEVICE, "k_gmm_run: a bounded wait expired (code %u); results discarded", gave_up);
+  }
   gmm_combine(c, (double*)c->h_pin + pin_layout(c).moments, probability);
   c->last_gmm_count = count;
   c->last_gmm_wp = c->W - 1;
@@ -1000,6 +1049,7 @@ int pocs_set_option(pocs_ctx* c, int option, long long value) {
     case POCS_OPT_MC_FUSED: c->opt_fused = value ? 1 : 0; break;
     case POCS_OPT_USE_GRAPH: c->opt_graph = value ? 1 : 0; break;
     case POCS_OPT_PROFILE: c->opt_profile = value ? 1 : 0; break;
+    case POCS_OPT_PERSISTENT: c->opt_persistent = value ? 1 : 0; break;
     case POCS_OPT_RUN_AHEAD:
       if (value < 1 || value > 256) return fail(c, POCS_E_ARG, "run-ahead %lld outside 1..256", value);
       c->run_ahead = (int)value;
@@ -1165,7 +1215,7 @@ int pocs_gmm_sample_local(pocs_ctx* c, int w) {
   if (w != c->last_gmm_adv) return fail(c, POCS_E_ORDER, "waypoint %d sampled before pocs_gmm_advance_local(%d)", w, w);
   long long first, count;
   if (int r = gmm_shard(c, &first, &count)) return r;
-  if (int r = enqueue_step(c, grid_for(count, c->batch, c->K), first, count, w, false, c->opt_profile ? w : -1)) return r;
+  if (int r = enqueue_step(c, first, count, w, false, c->opt_profile ? w : -1)) return r;
   c->last_gmm_wp = w;
   c->last_gmm_count = count;
   return POCS_OK;

@@ -7,14 +7,22 @@
 #include "pocs_model.h"
 
 #define POCS_BLOCK 256        // MC kernels
-// k_gmm_step: ONE block per CU.  The kernel holds one component's sums per thread whatever K is
-// (~149 VGPRs unconstrained).  1024 threads = four waves per SIMD at <= 128 VGPRs measured faster up
-// to K = 5 in spite of ~20 spilled registers (+3 %), 768 threads = three waves beyond (K = 8: +2 %).
+// GMM kernels: TWO blocks per CU.  The sampling body keeps one component's sums per thread whatever
+// K is; 2 x 512 threads = four waves per SIMD at <= 128 VGPRs up to K = 5, 2 x 384 = three waves
+// beyond (the K = 8 instantiation wants more registers).  Two co-resident blocks instead of one fat
+// one: while one block is in the head or tail of a task (parameter staging, block reduction, the
+// drain of its stores, ticket, mixture advance) the other block's waves have the CU's issue slots.
 #ifdef POCS_GMM_BLOCK                      // sweeps: force one size for every K
 #define POCS_GMM_BLOCK_OF(K) (POCS_GMM_BLOCK)
 #else
-#define POCS_GMM_BLOCK_OF(K) ((K) <= 5 ? 1024 : 768)
+#define POCS_GMM_BLOCK_OF(K) ((K) <= 5 ? 512 : 384)
 #endif
+#ifdef POCS_GMM_BPC                        // sweeps
+#define POCS_GMM_BLOCKS_PER_CU POCS_GMM_BPC
+#else
+#define POCS_GMM_BLOCKS_PER_CU 2
+#endif
+#define POCS_NUM_CUS 256
 #define POCS_MAX_BLOCKS 2048
 // chain record (doubles), one per step i < W-1:
 //   [0..2] applied control   [3..5] diag of M   [6..8] the noisy control actually driven (MC)
@@ -46,8 +54,11 @@ struct pocs_gmm_launch {
   double* state;                 // [nruns][W][K*POCS_STATE_STRIDE]  mixture sampled at each waypoint
   double* param;                 // [nruns][W][K*POCS_PARAM_STRIDE]  its sampler parameters (incl. the cumulative component counts)
   double* moments;               // [W][nruns][K*POCS_NMOM]          reduced moments of each waypoint
-  double* partial;               // [nruns][gridDim.x][K*POCS_NMOM]  block partials of this launch
-  unsigned* ticket;              // [nruns][W] arrival counters, zeroed once per batch
+  double* partial;               // [nruns][slices][K*POCS_NMOM]     partial row of task (run, slice); reused every waypoint
+  unsigned* sync;                // the call's synchronisation words, zeroed once per call: [0] task queue head,
+                                 // [1] give-up code of a bounded wait (0 = none), [4 + r] `ready` = waypoints of run r
+                                 // whose sampler parameters are published (k_gmm_run)
+  unsigned* ticket;              // [nruns][W] arrival counters of the tasks of (run, waypoint); same zeroed block
   double* x; double* y; double* th;   // SoA sample buffers [nruns][sample_stride] (unused when !store)
   int16_t* flags;
   long long n_total;             // samples of the whole mixture (all shards): what the component counts add up to
@@ -61,7 +72,14 @@ struct pocs_gmm_launch {
   int waypoint;
   int store;
   int advance_in_tail;           // 1: the last block also builds state/param[waypoint+1] (single GPU)
+  // task geometry: a chunk = POCS_GMM_BLOCK_OF(K) pairs of samples (one iteration of a block); slice j of
+  // a run = chunks [j*chunks/slices, (j+1)*chunks/slices); task (w, r, j) = slice j of run r at waypoint w
+  int slices;
+  long long chunks;
 };
+#define POCS_SYNC_HEAD 0
+#define POCS_SYNC_ABORT 1
+#define POCS_SYNC_READY 4
 
 struct pocs_mc_launch {               // blockIdx.y = run of the batch, like pocs_gmm_launch
   const pocs_run_header* hdr;          // [nruns]
@@ -81,7 +99,8 @@ struct pocs_mc_launch {               // blockIdx.y = run of the batch, like poc
   int nontemporal;                     // k_mc_step: the batch's state exceeds the Infinity Cache, stream past it
 };
 
-hipError_t pocs_launch_gmm_step(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);
+hipError_t pocs_launch_gmm_step(int K, const pocs_gmm_launch& a, hipStream_t s);              // grid = (a.slices, a.nruns)
+hipError_t pocs_launch_gmm_run(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);    // persistent: all W waypoints
 hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t s);
 hipError_t pocs_launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);
 hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s);

@@ -177,20 +177,32 @@ def test_gmm_one_million_samples_within_1e6(ctx, orc, plan, env):
 
 
 def test_gmm_variants_agree(ctx, pocs, plan, env):
-    """graph replay vs eager launches vs no sample store vs the per-waypoint step API."""
+    """The whole run in one launch (k_gmm_run, the default) vs one launch per waypoint (k_gmm_step),
+    graph replay vs eager launches, with and without the sample store, and the per-waypoint step
+    API: the same tasks with the same arithmetic, so everything is bitwise the same."""
     ctx.configure(plan, env, K=3, N=20000, seed=11)
     base = ctx.run_gmm_estimation()
     base_probs = ctx.waypoint_probabilities().copy()
     base_m = ctx.moments(30, 3).copy()
-    for opt, val in ((pocs.OPT_USE_GRAPH, 0), (pocs.OPT_STORE_SAMPLES, 0), (pocs.OPT_PROFILE, 1)):
+    base_xyz, base_flags = ctx.gmm_samples(20000)
+    for opt, val in ((pocs.OPT_USE_GRAPH, 0), (pocs.OPT_STORE_SAMPLES, 0), (pocs.OPT_PROFILE, 1), (pocs.OPT_PERSISTENT, 0)):
         ctx.set_option(opt, val)
         ctx.set_seed(11)
         assert ctx.run_gmm_estimation() == base
         assert np.array_equal(ctx.waypoint_probabilities(), base_probs)
         assert np.array_equal(ctx.moments(30, 3), base_m)        # fixed-shape reduction: bitwise
+        if opt == pocs.OPT_PROFILE:
+            ms, n = ctx.kernel_time()
+            assert n == 1 and ms > 0                             # ONE launch covers the 56 waypoints
+        if opt == pocs.OPT_PERSISTENT:
+            xyz, flags = ctx.gmm_samples(20000)
+            assert np.array_equal(xyz, base_xyz) and np.array_equal(flags, base_flags)
+            ctx.set_option(pocs.OPT_PROFILE, 1)
+            ctx.set_seed(11)
+            assert ctx.run_gmm_estimation() == base
+            assert ctx.kernel_time()[1] == 56                    # one launch per waypoint
+            ctx.set_option(pocs.OPT_PROFILE, 0)
         ctx.set_option(opt, 1 - val)
-    ms, n = ctx.kernel_time()
-    assert n == 56 and ms > 0
     ctx.set_seed(11)
     again = ctx.run_gmm_estimation()                             # graph replayed a second time
     assert again == base
@@ -199,6 +211,33 @@ def test_gmm_variants_agree(ctx, pocs, plan, env):
     for w in range(56):
         ctx.gmm_step_local(w)
     assert ctx.gmm_end() == base
+
+
+@pytest.mark.parametrize("K,N,R", [(3, 300000, 7), (8, 150000, 3), (1, 2_000_000, 1), (2, 40001, 20)])
+def test_persistent_kernel_under_uneven_load(pocs, plan, env, K, N, R):
+    """k_gmm_run hands its tasks out from a queue and carries the waypoint dependency of each run in a
+    `ready` word; which block runs what, and when, varies from launch to launch.  Sizes chosen so that
+    runs finish their waypoints at different times and blocks meet parameters published by other
+    blocks: every repetition must be bitwise what one launch per waypoint gives (moments of every
+    waypoint and run, states, last samples), and bitwise the same again."""
+    with pocs.Context(0) as c:
+        c.configure(plan, env, K=K, N=N, seed=123)
+        c.set_batch(R)
+        c.set_option(pocs.OPT_PERSISTENT, 0)
+        c.run_gmm_estimation()
+        want_p = list(c.batch_probabilities())
+        want_m = np.array([c.moments(w, K) for w in range(56)])
+        want_s = c.gmm_state_raw(55, K).copy()
+        want_x, want_f = c.gmm_samples(N)
+        c.set_option(pocs.OPT_PERSISTENT, 1)
+        for rep in range(4):
+            c.set_seed(123)
+            c.run_gmm_estimation()
+            assert list(c.batch_probabilities()) == want_p, rep
+            assert np.array_equal(np.array([c.moments(w, K) for w in range(56)]), want_m), rep
+            assert np.array_equal(c.gmm_state_raw(55, K), want_s), rep
+            x, f = c.gmm_samples(N)
+            assert np.array_equal(f, want_f) and np.array_equal(x, want_x), rep
 
 
 def test_batch_equals_consecutive_single_runs(ctx, plan, env):
