@@ -166,8 +166,8 @@ def main():
             c.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
         if os.environ.get("POCS_NO_GRAPH") == "1":       # diagnostic builds that synchronise inside the launch sequence
             c.set_option(pocs_amd.OPT_USE_GRAPH, 0)
-        if os.environ.get("POCS_PERSISTENT") == "0":     # A/B: one launch per waypoint instead of k_gmm_run
-            c.set_option(pocs_amd.OPT_PERSISTENT, 0)
+        if os.environ.get("POCS_PERSISTENT") == "1":     # A/B: the whole run as one queue-driven launch (k_gmm_run)
+            c.set_option(pocs_amd.OPT_PERSISTENT, 1)
         if sharded:     # one rank per GPU: launches on a torch stream, moments in a torch tensor
             return c, par.GpuEngine(c, W, K, N, rank=rank, world=world, per_rank=n_local, batch=b, stream=stream)
         c.set_batch(b)
@@ -250,8 +250,7 @@ def main():
     kern = "k_gmm_step" if path == "gmm" else ("k_mc_fused" if args.mc_fused else "k_mc_step")
     bpe = BYTES_PER_EVAL_GMM if path == "gmm" else BYTES_PER_EVAL_MC
     avg_ms = ms_tot / max(n_launch, 1)
-    persistent = (path == "gmm" and not sharded and os.environ.get("POCS_PERSISTENT", "1") != "0" and
-                  batch >= int(os.environ.get("POCS_PERSISTENT_MIN_RUNS", "16")))
+    persistent = path == "gmm" and not sharded and os.environ.get("POCS_PERSISTENT") == "1"
     kern = "k_gmm_run" if persistent else kern
     # evaluations one launch of the hot kernel processes: k_gmm_run covers all W waypoints of the batch
     units = n_local * batch * (W if persistent else 1)

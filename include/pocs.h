@@ -77,10 +77,11 @@ int pocs_send_command(pocs_ctx* ctx, const char* line, char* out, size_t cap);
                                       reference driver's one-command-per-run loop (MCSimulation.py:238-256) at batch throughput.
                                       Same runs, same seeds, same results and getters as one launch per run; any setter ends the
                                       serving and the run counter resumes after the last run handed out.  Text: setRunAhead R */
-#define POCS_OPT_PERSISTENT 6      /* 1 (default): a call that advances >= 16 runs (batch or run-ahead) is ONE launch for all W
-                                      waypoints of all of them (k_gmm_run: tasks from a queue, per-run `ready` words instead of
-                                      launch boundaries); fewer runs, or 0: one launch per waypoint (k_gmm_step + in-tail
-                                      mixture advance).  Same tasks, same arithmetic, bitwise the same results. */
+#define POCS_OPT_PERSISTENT 6      /* 0 (default): one launch per waypoint (k_gmm_step + in-tail mixture advance);
+                                      1: the whole call -- all W waypoints of all its runs -- is ONE queue-driven launch (k_gmm_run:
+                                      per-run `ready` words instead of launch boundaries).  Same tasks, same arithmetic, bitwise
+                                      the same results; on MI355X the per-waypoint form is as fast from 64 runs per call and
+                                      faster below, hence the default. */
 int pocs_set_option(pocs_ctx* ctx, int option, long long value);
 
 /* ---- batches of independent runs (ours) --------------------------------------------------

@@ -58,7 +58,7 @@ struct pocs_ctx {
   std::vector<double> boxes;             // M x 5
   bool have_obstacles = false;           // pocs_set_obstacles / addObstacle / clearObstacles was called at least once
   long long shard_first = -1, shard_count = -1;
-  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0, opt_persistent = 1;
+  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0, opt_persistent = 0;
   unsigned long long epoch = 0;          // bumped by every setter; part of the graph cache key
   int batch = 1;                         // independent GMM estimations advanced in lockstep per call
   // run-ahead (POCS_OPT_RUN_AHEAD): with batch == 1 a run* call evaluates the next `run_ahead` runs
@@ -173,10 +173,17 @@ int grid_blocks(long long count, int block, int default_bpc) {
 }
 // Task geometry of the GMM kernels (pocs_kernels.h): a chunk = one block iteration = TB pairs of
 // samples; a run's `chunks` are cut into `slices` contiguous ranges; task (w, r, j) = slice j of run r
-// at waypoint w.  Tasks per waypoint = runs x slices ~ 1.5 x the blocks resident on the chip, so that
-// a block leaving a task finds another one ready while the closing block of a run reduces and
-// advances its mixture (k_gmm_run), and a one-waypoint launch (k_gmm_step) fills the chip about evenly.
-// One run alone: as many slices as resident blocks.  POCS_SLICES overrides for sweeps.
+// at waypoint w = one block of a k_gmm_step launch.
+//   k_gmm_step  The chip takes blocks 256 at a time (one more per CU) and holds 512 of these: a launch
+//               of runs x slices <= 512 blocks runs as one resident set, and a handful over a multiple
+//               of 256 costs a whole extra block time (measured, 20 runs x 10^6 samples: 25 slices =
+//               500 blocks 1.12, 26 slices = 520 blocks 0.91 x 10^11 evals/s).  So: as many slices as
+//               keep runs x slices <= 512 (<= 256 below 8 runs: fewer, fatter blocks amortise head and
+//               tail better when the launch is short anyway).
+//   k_gmm_run   runs the same tasks (so that both kernels give bitwise the same sums) from a queue, on
+//               min(tasks per waypoint, 512) resident blocks; left to itself it would rather have ~2.5 x
+//               512 tasks per waypoint (sweeps: POCS_SLICES).
+// POCS_SLICES / POCS_RUN_BLOCKS override for sweeps.
 struct GmmGeometry { long long chunks; int slices; int blocks; };
 GmmGeometry gmm_geometry(long long count, int runs, int K) {
   static int forced = -1, forced_blocks = -1;
@@ -194,7 +201,7 @@ GmmGeometry gmm_geometry(long long count, int runs, int K) {
   g.chunks = (npairs + tb - 1) / tb;
   if (g.chunks < 1) g.chunks = 1;
   const int resident = POCS_NUM_CUS * POCS_GMM_BLOCKS_PER_CU;
-  long long want = runs <= 1 ? resident : (3LL * resident / 2 + runs - 1) / runs;
+  long long want = (runs >= 8 ? resident : POCS_NUM_CUS) / (runs > 0 ? runs : 1);
   if (forced) want = forced;
   if (want < 1) want = 1;
   if (want > g.chunks) want = g.chunks;
@@ -584,20 +591,16 @@ int enqueue_ticket_reset(pocs_ctx* c) {
   return POCS_OK;
 }
 
-// k_gmm_run or one k_gmm_step per waypoint?  The queue-driven kernel needs enough independent runs in
-// flight to cover the ~30 us in which the closing block of a run reduces and advances its mixture:
-// measured on MI355X (10^6 samples, K = 3) it wins from about 16 runs per call (20 runs: 1.06 vs
-// 0.98 x 10^11 evals/s; 64: equal) and loses below (8 runs: 0.67 vs 0.89; 1 run: 0.15 vs 0.34).
-// POCS_OPT_PERSISTENT = 0 forces the per-waypoint form, POCS_PERSISTENT_MIN_RUNS moves the threshold.
-bool use_persistent(const pocs_ctx* c) {
-  static int min_runs = -1;
-  if (min_runs < 0) {
-    const char* e = getenv("POCS_PERSISTENT_MIN_RUNS");
-    min_runs = e ? atoi(e) : 16;
-    if (min_runs < 1) min_runs = 1;
-  }
-  return c->opt_persistent && c->batch >= min_runs;
-}
+// k_gmm_run (the whole run in one queue-driven launch) or one k_gmm_step per waypoint?  Same tasks, same
+// arithmetic, bitwise the same results; which is faster is a matter of latency.  Measured on MI355X
+// (10^6 samples, K = 3): 64 runs per call 1.29 x 10^11 evals/s either way; 20 runs 1.00 (k_gmm_run) vs
+// 1.12; 8 runs 0.63 vs 0.95.  While the chip streams samples at 3 TB/s a memory round trip inside the
+// launch costs ~3 us instead of ~1, and closing a run's waypoint takes a dozen of them in a row
+// (ticket, acquire, the run's partial rows, the mixture's inputs, its stores, `ready`, and the same
+// again on the side that waits for it) -- with fewer than ~50 runs in flight that chain, not the
+// sampling, sets the pace.  The per-waypoint form pays them on an idle chip.  Hence: k_gmm_step by
+// default, k_gmm_run behind POCS_OPT_PERSISTENT.
+bool use_persistent(const pocs_ctx* c) { return c->opt_persistent != 0 && !c->ext_moments; }
 // How many launches of the hot kernel one whole-run call makes (what POCS_OPT_PROFILE brackets).
 size_t gmm_hot_launches(const pocs_ctx* c) { return use_persistent(c) ? 1 : (size_t)c->W; }
 

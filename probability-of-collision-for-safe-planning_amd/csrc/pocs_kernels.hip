@@ -143,16 +143,12 @@ __device__ __forceinline__ void acquire_agent() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the invalidate completes before the barrier releases the readers
 }
 
-#if defined(POCS_TASK_STAMPS)     // diagnostic build (tools/task_stamps.sh): where a block of k_gmm_run spends its time
+#if defined(POCS_TASK_STAMPS)     // diagnostic build (tools/task_stamps.sh): where a WAVE of k_gmm_run spends its time
 #include <stdio.h>
-__device__ unsigned long long g_stamps[16];
-#define POCS_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); st_[i] += n_ - last_; last_ = n_; } } while (0)
-#define POCS_STAMP_ARGS , unsigned long long (&st_)[12], unsigned long long& last_
-#define POCS_STAMP_PASS , st_, last_
+__device__ unsigned long long g_stamps[32];
+#define POCS_STAMP(i) do { const unsigned long long n_ = wall_clock64(); st_[i] += n_ - last_; last_ = n_; } while (0)
 #else
 #define POCS_STAMP(i) do { } while (0)
-#define POCS_STAMP_ARGS
-#define POCS_STAMP_PASS
 #endif
 
 // LDS scratch of the mixture advance (doubles): state[w-1], moments, chain record, sensor, state[w], param[w];
@@ -161,32 +157,41 @@ __device__ unsigned long long g_stamps[16];
                              (int)(sizeof(pocs_sensor) / sizeof(double)))
 #define POCS_SPEC_SCRATCH(K) ((K) * (POCS_STATE_STRIDE + 2))
 
-// LDS of the GMM kernels (one struct so that the shared pieces below can be handed around).
-template <int K, int TB>
+// LDS of the GMM kernels.  NB = task buffers: 1 for k_gmm_step (one task per block), 3 for k_gmm_run
+// (the waves of a block drift up to a task apart, see there).
+template <int K, int TB, int NB>
 struct gmm_smem {
   static constexpr int NC = K * POCS_NMOM;
-  alignas(16) pocs_tables tab;                                   // 12 KB log / sector tables, staged once per block
-  alignas(16) double obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];  // obstacle table, staged once per block
-  // per task, double-buffered: k_gmm_run stages the NEXT task's copy while the current one is sampled
-  alignas(16) double keep[2][POCS_MAX_OBSTACLES * POCS_OBS_STRIDE]; // obstacle table culled for the task
-  alignas(16) double par[2][K * POCS_PARAM_STRIDE];                 // sampler parameters of (run, waypoint)
-  double red[TB / 16][NC];                                       // one row of sums per 16-lane DPP row
-  double part[TB];
-  double adv[POCS_ADV_SCRATCH(K)];                               // mixture advance: inputs and outputs
+  static constexpr int RB = TB / 16;                                 // rows of sums per task: one per 16-lane DPP row
+  alignas(16) pocs_tables tab;                                       // 12 KB log / sector tables, staged once per block
+  alignas(16) double obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];      // obstacle table, staged once per block
+  alignas(16) double keep[NB][POCS_MAX_OBSTACLES * POCS_OBS_STRIDE]; // ... culled for a task
+  alignas(16) double par[NB][K * POCS_PARAM_STRIDE];                 // sampler parameters of the task's (run, waypoint)
+  double red[NB][RB][NC];                                            // the task's row sums; staging area of its closer
+  double adv[POCS_ADV_SCRATCH(K)];                                   // mixture advance: inputs and outputs
   double spec[POCS_SPEC_SCRATCH(K)];
-  int nkeep[2];
-  int last;
-  unsigned next_task;      // k_gmm_run: the task this block runs next ...
-  unsigned next_state;     // ... 1 = dequeued only, 2 = parameters + culled table already staged in buffer buf ^ 1
-  unsigned go;
+  double tot[NC];
+  int nkeep[NB];
+  int last;                 // k_gmm_step: this block drew the last ticket
+  // k_gmm_run, the block's task pipeline: buffer b = n % NB holds the block's n-th task
+  unsigned long long seed[NB];      // what every wave needs of it, worked out once by the loader: the run's seed,
+  long long c_begin[NB], c_end[NB]; // its chunk range,
+  int tw[NB], tr[NB], tslot[NB];    // waypoint, run, slice
+  unsigned task_id[NB];     // its number in the launch's queue (>= total: no more tasks, leave)
+  unsigned seq[NB];         // n + 1 once wave 0 has staged it (parameters, culled table)
+  unsigned done[NB];        // waves that have sampled their share of it and drained their stores
+  unsigned freed[NB];       // n + 1 once its closing wave is through with the buffer
+  unsigned lock;            // the advance scratch above is one wave's at a time
+  unsigned quit;            // a bounded wait expired somewhere: everybody leaves
 };
 
 // Mixture bookkeeping of waypoint `w` (pocs_gmm_advance_component / pocs_gmm_normalise): every input
 // (state[w-1], the reduced moments of w-1, the chain record of step w-1, the sensor) is first brought
-// to LDS by the whole block in ONE round trip, lanes < K of wave 0 then take one component each
-// (truncated mean / covariance, EKF predict + update, Cholesky) while a lane of wave 1 draws the
-// component counts as they will come out unless a factorisation fails; lane 0 normalises and the
-// wave writes state[w] / param[w] back write-through.
+// to LDS in ONE round trip, lanes < K of one wave then take one component each (truncated mean /
+// covariance, EKF predict + update, Cholesky); lane 0 normalises, draws the component counts, and the
+// wave writes state[w] / param[w] back write-through.  Run by a whole block (k_gmm_advance,
+// k_gmm_step: a lane of a second wave draws the counts meanwhile, on the premise -- checked -- that
+// no factorisation fails) or by a single wave (k_gmm_run); same functions, same results.
 struct adv_ptrs {
   double *l_prev, *l_mom, *l_ch, *l_sen, *l_next, *l_par;
   double *g_state, *g_param;
@@ -214,20 +219,40 @@ __device__ __forceinline__ adv_ptrs advance_ptrs(const pocs_gmm_launch& a, int K
   return p;
 }
 
-// All threads of the block.  mom_in_lds: l_mom already holds the moments of w-1 (the block has just
-// reduced them); otherwise they are read from a.moments (own launch: after the caller's all-reduce).
-// state[w-1] may have been written by another block of THIS launch: L1-bypassing loads.
+// n values src(0) .. src(n-1) -> stage[0 .. n-1] by `nthreads` threads, U loads in flight per thread:
+// the loads of a batch are all issued before the first of them is waited for (a plain copy loop waits
+// for every load before it issues the next one: one memory round trip per element and thread).
+template <int U, typename Src>
+__device__ __forceinline__ void stage_batched(double* stage, const int n, const int tid, const int nthreads, Src src) {
+  for (int i0 = tid; i0 < n; i0 += nthreads * U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int i = i0 + u * nthreads; v[u] = (i < n) ? src(i) : 0.0; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int i = i0 + u * nthreads; if (i < n) stage[i] = v[u]; }
+  }
+}
+
+// `nthreads` threads (tid < nthreads).  mom_in_lds: l_mom already holds the moments of w-1 (the caller
+// has just reduced them); otherwise they are read from a.moments (own launch: after the caller's
+// all-reduce).  state[w-1] may have been written by another block of THIS launch: L1-bypassing loads.
+// One batch of loads for everything (the scratch is laid out l_prev | l_mom | l_ch | l_sen).
 __device__ __forceinline__ void advance_stage(const pocs_gmm_launch& a, int K, int w, int r, double* scratch,
                                               bool mom_in_lds, int tid, int nthreads) {
   const adv_ptrs p = advance_ptrs(a, K, w, r, scratch);
   constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
-  for (int j = tid; j < p.ss; j += nthreads) p.l_prev[j] = load_wt(&p.g_prev[j]);
-  if (w > 0 && !mom_in_lds) for (int j = tid; j < p.NC; j += nthreads) p.l_mom[j] = p.g_mom[j];
-  for (int j = tid; j < POCS_CHAIN_STRIDE; j += nthreads) p.l_ch[j] = p.g_ch[j];
-  for (int j = tid; j < SEN; j += nthreads) p.l_sen[j] = p.g_sen[j];
+  const int ss = p.ss, NC = p.NC;
+  const bool load_mom = w > 0 && !mom_in_lds;
+  const int n = ss + POCS_CHAIN_STRIDE + SEN;
+  stage_batched<4>(scratch, n + NC, tid, nthreads, [&](int i) -> double {
+    if (i < ss) return load_wt(&p.g_prev[i]);
+    if (i < ss + NC) return load_mom ? p.g_mom[i - ss] : p.l_mom[i - ss];     // in LDS already: rewritten with itself
+    if (i < ss + NC + POCS_CHAIN_STRIDE) return p.g_ch[i - ss - NC];
+    return p.g_sen[i - ss - NC - POCS_CHAIN_STRIDE];
+  });
 }
 
-// wave 0, after advance_stage + barrier: one component per lane
+// one wave, after advance_stage (+ barrier): one component per lane
 __device__ __forceinline__ void advance_components(const pocs_gmm_launch& a, int K, int w, int r, int lane, double* scratch) {
   const adv_ptrs p = advance_ptrs(a, K, w, r, scratch);
   if (lane < K)
@@ -252,8 +277,8 @@ __device__ __forceinline__ void speculate_counts(const pocs_gmm_launch& a, int K
   pocs_component_counts(K, st, last_alive, a.hdr[r].seed, (uint32_t)w, (double)a.n_total, spec, 1);
 }
 
-// wave 0, after a barrier: weights, component counts (the speculated ones if their premise held),
-// write-through stores of state[w] / param[w], drained.
+// the wave of advance_components, after it (+ barrier): weights, component counts (the speculated ones
+// if there are any and their premise held), write-through stores of state[w] / param[w], drained.
 __device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, int w, int r, int lane, double* scratch,
                                                const double* spec) {
   const adv_ptrs p = advance_ptrs(a, K, w, r, scratch);
@@ -284,6 +309,16 @@ __device__ __forceinline__ void advance_block(const pocs_gmm_launch& a, int K, i
   __syncthreads();
   if (tid < 64) advance_finish(a, K, w, r, tid, adv, w > 0 ? spec : nullptr);
 }
+// ... and by ONE wave (all 64 lanes call it), the moments of w-1 already in l_mom.
+__device__ __forceinline__ void advance_wave(const pocs_gmm_launch& a, int K, int w, int r, double* adv, int lane) {
+  advance_stage(a, K, w, r, adv, true, lane, 64);
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+  advance_components(a, K, w, r, lane, adv);
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+  advance_finish(a, K, w, r, lane, adv, nullptr);
+}
 
 __global__ __launch_bounds__(128) void k_gmm_advance(pocs_gmm_launch a, int K) {
   __shared__ double s_adv[POCS_ADV_SCRATCH(POCS_MAX_GAUSSIANS)];
@@ -291,30 +326,27 @@ __global__ __launch_bounds__(128) void k_gmm_advance(pocs_gmm_launch a, int K) {
   advance_block(a, K, a.waypoint, blockIdx.x, s_adv, s_spec, false, threadIdx.x, 128);      // one block per run
 }
 
-// A wave leaves component `k`: its 16-lane row sums of (nFree, nColl, 9 sums) are ADDED to the
-// block's LDS rows of that component (every wave owns its rows; a wave meets a component once,
-// the add only matters for a component it never touched: + 0) and the thread-private sums restart.
-template <int TB, int NC>
-__device__ __forceinline__ void flush_component(double (*s_red)[NC], int k, double (&acc)[9], unsigned& nfree,
-                                                unsigned& ncoll, int tid) {
+// A wave leaves component `k`: its 16-lane row sums of (nFree, 9 sums) are ADDED to the task's LDS
+// rows of that component -- every 16-lane row of threads owns one row of sums, a wave meets a component
+// once per task, the add only matters for a component it never touched (+ 0) -- and the thread-private
+// sums restart.  Column 1 of a row (nColl) stays 0: the collisions of a component are what is left of
+// its block of samples (gmm_close_sums).
+template <int NC>
+__device__ __forceinline__ void flush_component(double (*s_red)[NC], int k, double (&acc)[10], int tid) {
   const int row = tid >> 4;
   const bool writer = (tid & 15) == 0;
-  const unsigned nf = row_sum_u32(nfree);
-  const unsigned nc = row_sum_u32(ncoll);
   double* dst = &s_red[row][k * POCS_NMOM];
-  if (writer) { dst[0] += (double)nf; dst[1] += (double)nc; }
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {
+  for (int j = 0; j < 10; ++j) {
     const double v = row_sum(acc[j]);
-    if (writer) dst[2 + j] += v;
+    if (writer) dst[j == 0 ? 0 : 1 + j] += v;
     acc[j] = 0.0;
   }
-  nfree = 0u; ncoll = 0u;
 }
 
 // Once per block: the log / sector tables and the obstacle table -> LDS.
-template <int K, int TB>
-__device__ __forceinline__ void gmm_stage_static(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm) {
+template <int K, int TB, int NB>
+__device__ __forceinline__ void gmm_stage_static(const pocs_gmm_launch& a, gmm_smem<K, TB, NB>& sm) {
   stage_tables(a.tables, &sm.tab);
   for (int j = threadIdx.x; j < a.M * POCS_OBS_STRIDE; j += TB) sm.obs[j] = a.env->obs[j];
 }
@@ -325,8 +357,8 @@ __device__ __forceinline__ void gmm_stage_static(const pocs_gmm_launch& a, gmm_s
 // draw lies within mean_k +- 6.67 (|L00|, |L10|+|L11|) of some component; an obstacle whose inflated
 // box (the broad phase of pocs_box_hit) misses that region is rejected by the broad phase for every
 // sample, so dropping it here changes no flag.
-template <int K, int TB>
-__device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm, const int buf, const int lane) {
+template <int K, int TB, int NB>
+__device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, TB, NB>& sm, const int buf, const int lane) {
   const pocs_footprint fp = a.fp;
   const int M = a.M;
   double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
@@ -353,106 +385,39 @@ __device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, T
   if (lane == 0) sm.nkeep[buf] = __popcll(mask);
 }
 
-// The whole block stages task (w, r) into buffer `buf`: sampler parameters (they may have been
-// published by another block of this launch: L1-bypassing loads, behind the caller's acquire) and
-// the culled obstacle table.  Ends without a barrier: gmm_task's head has one.
-template <int K, int TB>
-__device__ __forceinline__ void gmm_stage_task(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm, const int buf, const int w, const int r) {
-  const int tid = threadIdx.x;
-  for (int j = tid; j < K * POCS_PARAM_STRIDE; j += TB)
-    sm.par[buf][j] = load_wt(&a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j]);
-  __syncthreads();
-  if (tid < 64) gmm_cull<K, TB>(a, sm, buf, tid);
-}
-
-// k_gmm_run, wave 0 of a block: take the block's NEXT task from the queue and, if its parameters are
-// already published (w == 0, or ready[r] >= w: the usual case once the pipeline runs), stage them and
-// the culled table into buffer `nbuf` -- so the block goes from one body straight into the next.
-// Called twice per task.  FIRST at the start of the body, when the wave has no sample stores in flight
-// yet: a wave's loads, atomics and stores complete in issue order, and write-through stores are slow
-// to complete, so the same three dependent round trips (queue, `ready`, parameters) cost ~2 us each
-// here and ~5 us each behind a body's stores.  AGAIN after the wave's share of the body, if the task
-// was not published the first time (state 1): only then does the block still have to wait at the top
-// of its loop.
-template <int K, int TB>
-__device__ __forceinline__ void gmm_prefetch_next(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm, const int nbuf, const int lane,
-                                                  const bool dequeue) {
-  const unsigned per_wp = (unsigned)a.nruns * (unsigned)a.slices;
-  const unsigned total = per_wp * (unsigned)a.W;
-  unsigned t = 0u;
-  if (dequeue) {
-    if (lane == 0) {
-      t = __hip_atomic_fetch_add(&a.sync[POCS_SYNC_HEAD], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) t = 0xffffffffu;
-    }
-    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-  } else {
-    if ((unsigned)__builtin_amdgcn_readfirstlane((int)sm.next_state) == 2u) return;     // staged the first time
-    t = (unsigned)__builtin_amdgcn_readfirstlane((int)sm.next_task);
-  }
-  unsigned state = 1u;
-  if (t < total) {
-    const int w = __builtin_amdgcn_readfirstlane((int)(t / per_wp));
-    const int r = __builtin_amdgcn_readfirstlane((int)((t - (unsigned)w * per_wp) / (unsigned)a.slices));
-    bool ready = (w == 0);
-    if (!ready) {
-      unsigned have = 0u;
-      if (lane == 0) have = __hip_atomic_load(&a.sync[POCS_SYNC_READY + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ready = (unsigned)__builtin_amdgcn_readfirstlane((int)have) >= (unsigned)w;
-      if (ready) acquire_agent();                                // the poll matched: ONE acquire, then the loads
-    }
-    if (ready) {
-      for (int j = lane; j < K * POCS_PARAM_STRIDE; j += 64)
-        sm.par[nbuf][j] = load_wt(&a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j]);
-      __threadfence_block();
-      __builtin_amdgcn_wave_barrier();
-      gmm_cull<K, TB>(a, sm, nbuf, lane);
-      state = 2u;
-    }
-  }
-  if (lane == 0) { sm.next_task = t; sm.next_state = state; }
-}
-
 // ---------------------------------------------------------------------------------------------
-// ONE TASK = slice `slot` (of `a.slices`) of run r at waypoint w, by one block:
-//   head  sampler parameters of (r, w) -> LDS (they may have been published by another block of this
-//         launch: L1-bypassing loads behind the caller's acquire); exact culling of the obstacle
-//         table against the mixture's bounding box;
-//   body  GM_Model::sampleNPoints (GM_Model.h:83-116) + checkMatrixCollisions (MCSimulator.h:241-253)
-//         + the moment sums (:592-611), fused, one PAIR of samples per thread-iteration;
-//   tail  DPP row sums -> LDS rows -> ONE write-through partial row (r, slot) -> drain -> ticket (r, w).
-// Returns true in the block whose ticket was the last of (r, w) (that block has acquired).
-// The arithmetic of a task depends on (r, w, slot, a.slices, a.chunks) only -- not on which kernel
-// runs it, which block, or when: k_gmm_step and k_gmm_run give bitwise the same partial rows.
+// THE BODY of a task = slice `slot` (of a.slices) of run r at waypoint w, as every thread of the block
+// runs it: GM_Model::sampleNPoints (GM_Model.h:83-116) + checkMatrixCollisions (MCSimulator.h:241-253)
+// + the moment sums (:592-611), fused, one PAIR of samples per thread and iteration; ends with the
+// thread's sums folded into the task's LDS rows (each 16-lane row of threads owns one row: no
+// barrier in here).  s_par / s_keep / nkeep: the task's staged parameters and culled obstacle table.
+// WT: write-through sample stores (k_gmm_run).  What a thread computes depends on (r, w, slot,
+// a.slices, a.chunks, its tid) only -- not on the kernel, the block, or when: k_gmm_step and
+// k_gmm_run produce bitwise the same rows.  seed = the run's; [c_begin, c_end) = the slice's chunks
+// (gmm_slice_chunks), both wave-uniform.
 // ---------------------------------------------------------------------------------------------
 template <int K, bool STORE, bool WT, int TB>
-__device__ __forceinline__ bool gmm_task(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm, const int w, const int r, const int slot,
-                                         const int buf POCS_STAMP_ARGS) {
+__device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_tables* s_tab, const double* s_par,
+                                         const double* s_keep, const int nkeep, double (*s_red)[K * POCS_NMOM],
+                                         const int w, const int r, uint64_t seed, const long long c_begin, const long long c_end
+#if defined(POCS_TASK_STAMPS)
+                                         , unsigned long long (&st_)[12], unsigned long long& last_
+#endif
+                                         ) {
   constexpr int NC = K * POCS_NMOM;
   const int tid = threadIdx.x;
   const pocs_footprint fp = a.fp;
-
-  // ---- head: the task's sampler parameters and culled obstacle table are staged in buffer `buf`
-  uint64_t seed = a.hdr[r].seed;
-  seed = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(seed >> 32)) << 32) |
-         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seed);          // scalar registers, provably
+  seed = (uint64_t)uniform64((long long)seed);       // scalar registers, provably
   // Samples come in component blocks and a thread's sample indices only grow, so a wave works
   // through the components in order: ONE set of sums per thread (the wave's current component),
-  // folded into the block's LDS rows when the wave moves on to the next component.
-  double acc[9];
-  unsigned nfree = 0u, ncoll = 0u;
+  // folded into the task's LDS rows when the wave moves on to the next component.
+  //   acc[0] = survivors, acc[1..9] = sums of x, y, t, xx, xy, xt, yy, yt, tt over them
+  double acc[10];
   int kcur = 0;                                      // wave-uniform
 #pragma unroll
-  for (int j = 0; j < 9; ++j) acc[j] = 0.0;
-  for (int j = tid; j < (TB / 16) * NC; j += TB) (&sm.red[0][0])[j] = 0.0;
-  __syncthreads();
-  const double* const s_par = sm.par[buf];
-  const double* const s_keep = sm.keep[buf];
-  const int nkeep = __builtin_amdgcn_readfirstlane(sm.nkeep[buf]);     // a scalar loop bound for the obstacle loop
-  POCS_STAMP(1);
+  for (int j = 0; j < 10; ++j) acc[j] = 0.0;
+  for (int c = tid & 15; c < NC; c += 16) s_red[tid >> 4][c] = 0.0;      // this row of threads' own row of sums
 
-  // ---- body: one PAIR of samples (2j, 2j+1) per thread and iteration -- the pair shares two
-  // Philox draws = three Box-Muller pairs (pocs_normal3_pair) and its poses leave as 16-byte stores.
   // a.first is even (checked by the host), so local sample 2*lp is global sample first + 2*lp.
   const long long npairs = (a.count + 1) >> 1;
   const uint64_t pair0 = (uint64_t)(a.first >> 1);
@@ -466,20 +431,17 @@ __device__ __forceinline__ bool gmm_task(const pocs_gmm_launch& a, gmm_smem<K, T
   double* const yr = a.y + (size_t)r * a.sample_stride;
   double* const tr = a.th + (size_t)r * a.sample_stride;
   int16_t* const fr = a.flags + (size_t)r * a.sample_stride;
-  const long long c_begin = uniform64(((long long)slot * a.chunks) / a.slices);      // (64-bit division runs on the vector unit)
-  const long long c_end = uniform64(((long long)(slot + 1) * a.chunks) / a.slices);
-  if (WT && tid < 64) gmm_prefetch_next<K, TB>(a, sm, buf ^ 1, tid, true);       // k_gmm_run: the block's next task, see there
 #if !defined(POCS_NO_PRIO_ROTATION)
   // The (up to) four waves of a SIMD -- two of this block, two of the co-resident one -- are arbitrated
   // by priority, then AGE: left alone, the oldest wave of a SIMD runs ~1.7 x faster than the youngest for
-  // the whole launch, every task ends with its fast waves idle at the barrier and the SIMDs half empty.
-  // Rotating the priority with the iteration gives every wave the same share: they reach the barrier
-  // together.  slot = which of the block's two waves on this SIMD (waves v and v + TB/256 share one);
-  // the second block of a CU is (observed, speed only) the one dispatched 256 blocks later.
+  // the whole launch.  Rotating the priority with the iteration gives every wave the same share.
+  // slot = which of the block's waves on this SIMD (waves v and v + TB/256 share one); the second block
+  // of a CU is (observed, speed only) the one dispatched 256 blocks later.
   const int prio_slot = (TB >= 512 ? __builtin_amdgcn_readfirstlane((tid >> 6) / (TB / 256)) : 0) +
                         (TB >= 512 ? 2 : 1) * (int)(((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 3u);
   int prio_it = prio_slot;
 #endif
+  POCS_STAMP(2);
   for (long long base = c_begin * TB; base < c_end * TB; base += TB) {
 #if !defined(POCS_NO_PRIO_ROTATION)
     switch (prio_it++ & 3) {                       // s_setprio takes an immediate
@@ -507,7 +469,7 @@ __device__ __forceinline__ bool gmm_task(const pocs_gmm_launch& a, gmm_smem<K, T
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(seed_it));
 #endif
-    pocs_normal3_pair(seed_it, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, &sm.tab, zz[0], zz[1], &spare[0], &spare[1]);
+    pocs_normal3_pair(seed_it, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, s_tab, zz[0], zz[1], &spare[0], &spare[1]);
 #endif
     const long long i0 = 2 * lp;
     const bool two = live && (i0 + 1) < a.count;  // false only for the last sample of an odd shard
@@ -531,45 +493,46 @@ __device__ __forceinline__ bool gmm_task(const pocs_gmm_launch& a, gmm_smem<K, T
 #if defined(POCS_ABLATE_COLLIDE)
       const bool hit = x > t;
 #else
-      const bool hit = pocs_pose_collides(x, y, t, &fp, s_keep, nkeep, &sm.tab);
+      const bool hit = pocs_pose_collides(x, y, t, &fp, s_keep, nkeep, s_tab);
 #endif
       xs[h] = x; ys[h] = y; ts[h] = t; hits[h] = hit; ks[h] = k;
     }
 #if defined(POCS_ABLATE_MOMENTS)
-    acc[0] += xs[0] + ys[0] + ts[0] + xs[1]; nfree += hits[0] ? 0u : 1u; ncoll += (two && ks[1] == 0) ? 1u : 0u;
+    acc[1] += xs[0] + ys[0] + ts[0] + xs[1]; acc[0] += (hits[0] || (two && ks[1] == 0)) ? 0.0 : 1.0;
 #else
-    // T1 sums: acc += ind * (x, y, t, xx, xy, xt, yy, yt, tt) with ind = 1.0 for a collision-free
-    // sample of the component being accumulated, else 0.0 (fma(1, v, acc) == acc + v, fma(0, v, acc)
-    // == acc exactly).  A wave sits in ONE component block except where two blocks meet; the
-    // components present in the wave are visited in increasing order (scalar loop), the previous
-    // component's sums being flushed to the LDS rows first.
+    // T1 sums over the collision-free samples of the component being accumulated: with ind = 1.0 for
+    // such a sample and 0.0 otherwise, (xm, ym, tm) = ind * (x, y, t) and
+    //   acc += (ind, xm, ym, tm, xm x, xm y, xm t, ym y, ym t, tm t)      (the products inside the fma).
+    // A wave sits in ONE component block except where two blocks meet (and every lane is live except
+    // in a shard's last chunk): then ind is just "did not collide".  Otherwise the components present
+    // in the wave are visited in increasing order (scalar loop), the previous component's sums being
+    // flushed to the LDS rows first.
     {
       // sample indices grow with the lane: lane 0 holds the wave's first component, lane 63 its last
       const int klo = __builtin_amdgcn_readfirstlane(live ? ks[0] : K);
-      const int khi = (__ballot(live) == ~0ull) ? __builtin_amdgcn_readlane(ks[1], 63) : K - 1;
+      const bool all_two = __ballot(two) == ~0ull;
+      const int khi = all_two ? __builtin_amdgcn_readlane(ks[1], 63) : K - 1;
+      auto add = [&](const double ind, const double x, const double y, const double t) {
+        const double xm = ind * x, ym = ind * y, tm = ind * t;
+        acc[0] += ind;
+        acc[1] += xm; acc[2] += ym; acc[3] += tm;
+        acc[4] = fma(xm, x, acc[4]); acc[5] = fma(xm, y, acc[5]); acc[6] = fma(xm, t, acc[6]);
+        acc[7] = fma(ym, y, acc[7]); acc[8] = fma(ym, t, acc[8]); acc[9] = fma(tm, t, acc[9]);
+      };
+      if (all_two && klo == khi) {                                            // scalar condition: the usual case
+        if (klo != kcur) { flush_component<NC>(s_red, kcur, acc, tid); kcur = klo; }
 #pragma unroll
-      for (int kk = 0; kk < K; ++kk) {
-        if (kk < klo || kk > khi) continue;                                   // scalar compares
-        if (kk != kcur) {
-          flush_component<TB, NC>(sm.red, kcur, acc, nfree, ncoll, tid);
-          kcur = kk;
-        }
+        for (int h = 0; h < 2; ++h) add(hits[h] ? 0.0 : 1.0, xs[h], ys[h], ts[h]);
+      } else {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const bool sel = (h == 0 ? live : two) && ks[h] == kk;
-          const double x = xs[h], y = ys[h], t = ts[h];
-          nfree += (sel && !hits[h]) ? 1u : 0u;
-          ncoll += (sel && hits[h]) ? 1u : 0u;
-          const double ind = (sel && !hits[h]) ? 1.0 : 0.0;
-          acc[0] = fma(ind, x, acc[0]);
-          acc[1] = fma(ind, y, acc[1]);
-          acc[2] = fma(ind, t, acc[2]);
-          acc[3] = fma(ind, x * x, acc[3]);
-          acc[4] = fma(ind, x * y, acc[4]);
-          acc[5] = fma(ind, x * t, acc[5]);
-          acc[6] = fma(ind, y * y, acc[6]);
-          acc[7] = fma(ind, y * t, acc[7]);
-          acc[8] = fma(ind, t * t, acc[8]);
+        for (int kk = 0; kk < K; ++kk) {
+          if (kk < klo || kk > khi) continue;                                 // scalar compares
+          if (kk != kcur) { flush_component<NC>(s_red, kcur, acc, tid); kcur = kk; }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const bool sel = (h == 0 ? live : two) && ks[h] == kk;
+            add((sel && !hits[h]) ? 1.0 : 0.0, xs[h], ys[h], ts[h]);
+          }
         }
       }
     }
@@ -578,7 +541,7 @@ __device__ __forceinline__ bool gmm_task(const pocs_gmm_launch& a, gmm_smem<K, T
       // Both poses of the pair leave together.  For the last sample of an odd shard the second
       // slot is the pair's unused twin: it lands in the padding element of the run's slice
       // (sample_stride >= count + 1 then) and is never read back.  Written once, never re-read by
-      // the kernels: non-temporal, so the stream does not displace the tables / partial rows in L2.
+      // the kernels.
       const size_t ub = 2 * (size_t)base;
       const int fl = (hits[0] ? 1 : 0) | ((two && hits[1]) ? 0x10000 : 0);
       if (WT) {                                    // k_gmm_run: write-through, see store16_wt
@@ -586,7 +549,7 @@ __device__ __forceinline__ bool gmm_task(const pocs_gmm_launch& a, gmm_smem<K, T
         store16_wt(yr + ub, 16u * (unsigned)tid, (v2d){ys[0], ys[1]});
         store16_wt(tr + ub, 16u * (unsigned)tid, (v2d){ts[0], ts[1]});
         store4_wt(fr + ub, 4u * (unsigned)tid, fl);
-      } else {
+      } else {                                     // a launch per waypoint: non-temporal, past the caches
         __builtin_nontemporal_store((v2d){xs[0], xs[1]}, reinterpret_cast<v2d*>(xr + ub) + tid);
         __builtin_nontemporal_store((v2d){ys[0], ys[1]}, reinterpret_cast<v2d*>(yr + ub) + tid);
         __builtin_nontemporal_store((v2d){ts[0], ts[1]}, reinterpret_cast<v2d*>(tr + ub) + tid);
@@ -594,27 +557,104 @@ __device__ __forceinline__ bool gmm_task(const pocs_gmm_launch& a, gmm_smem<K, T
       }
     }
   }
-
-  // ---- tail: the last component's sums -> LDS rows; a fixed-order sum over the TB/16 rows -> the
-  // task's write-through partial row; every storing wave drains, the block meets, ONE lane takes the
-  // ticket of (r, w); the block that draws the last one acquires.
 #if !defined(POCS_NO_PRIO_ROTATION)
-  __builtin_amdgcn_s_setprio(0);
+  // Everything between two bodies -- flush, drain, closing a task, adding a run's rows, advancing its
+  // mixture, staging the next task -- is short and other waves (or blocks) wait for it: it runs at the
+  // TOP priority, or the sampling waves of the same SIMD (priority 0..3 in turn) leave it the crumbs.
+  __builtin_amdgcn_s_setprio(3);
 #endif
-  POCS_STAMP(2);
-  if (WT && tid < 64) gmm_prefetch_next<K, TB>(a, sm, buf ^ 1, tid, false);      // k_gmm_run: second try, if need be
-  flush_component<TB, NC>(sm.red, kcur, acc, nfree, ncoll, tid);
-  __syncthreads();
   POCS_STAMP(3);
-  if (tid < NC) {
-    double v = sm.red[0][tid];
+  flush_component<NC>(s_red, kcur, acc, tid);       // the last component's sums -> the LDS rows
+  POCS_STAMP(4);
+}
+
+// chunks [begin, end) of slice `slot`
+__device__ __forceinline__ void gmm_slice_chunks(const pocs_gmm_launch& a, const int slot, long long* begin, long long* end) {
+  *begin = ((long long)slot * a.chunks) / a.slices;
+  *end = ((long long)(slot + 1) * a.chunks) / a.slices;
+}
+
+// Column c of the task's partial row: the RB rows of sums added in row order.
+template <int NC, int RB>
+__device__ __forceinline__ double gmm_row_total(const double (*s_red)[NC], const int c) {
+  double v = s_red[0][c];
 #pragma unroll 8
-    for (int q = 1; q < TB / 16; ++q) v += sm.red[q][tid];
-    store_wt(&a.partial[((size_t)r * a.slices + slot) * NC + tid], v);
+  for (int q = 1; q < RB; ++q) v += s_red[q][c];
+  return v;
+}
+
+// The closer of (r, w) -- the block (k_gmm_step) or wave (k_gmm_run) that drew the run's last ticket,
+// behind its acquire -- adds the a.slices partial rows of the run IN SLICE ORDER, column by column:
+// `nthreads` threads bring RB rows at a time to `stage` (L1-bypassing loads, all in flight at once),
+// then thread c adds them to column c.  `sync` = the barrier of those threads.  The collisions of a
+// component are what is left of its block of this shard's samples: nColl_k = n_k - nFree_k, with
+// [cum_{k-1}, cum_k) the component's global sample range (par[k][9], cum_{K-1} = n_total).
+// Result: tot[c], and moments[w][r][c] in global memory (it leaves the launch at the kernel boundary).
+template <int K, int RB, typename Sync>
+__device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const int w, const int r, const double* s_par,
+                                               double* stage, double* tot, const int tid, const int nthreads, Sync sync) {
+  constexpr int NC = K * POCS_NMOM;
+  const int S = a.slices;
+  for (int c = tid; c < NC; c += nthreads) tot[c] = 0.0;
+  for (int b0 = 0; b0 < S; b0 += RB) {
+    const int nrow = (S - b0 < RB) ? S - b0 : RB;
+    const double* src = a.partial + ((size_t)r * S + b0) * NC;
+    stage_batched<8>(stage, nrow * NC, tid, nthreads, [&](int i) -> double { return load_wt(&src[i]); });
+    sync();
+    for (int c = tid; c < NC; c += nthreads) {
+      double v = tot[c];
+      for (int q = 0; q < nrow; ++q) v += stage[q * NC + c];
+      tot[c] = v;
+    }
+    sync();
   }
+  const double lo = (double)a.first, hi = (double)(a.first + a.count);
+  for (int k = tid; k < K; k += nthreads) {
+    const double c0 = (k == 0) ? 0.0 : s_par[(k - 1) * POCS_PARAM_STRIDE + 9];
+    const double c1 = (k == K - 1) ? (double)a.n_total : s_par[k * POCS_PARAM_STRIDE + 9];
+    const double n_k = fmax(0.0, fmin(c1, hi) - fmax(c0, lo));
+    tot[k * POCS_NMOM + 1] = n_k - tot[k * POCS_NMOM];
+  }
+  sync();
+  for (int c = tid; c < NC; c += nthreads) a.moments[((size_t)w * a.nruns + r) * NC + c] = tot[c];
+}
+
+// One waypoint as its own launch: grid = (slices, runs), block (j, r) = task (a.waypoint, r, j).  The
+// per-waypoint form, for a caller that exchanges the moments between waypoints (sharded over GPUs) and
+// for calls with too few runs to keep k_gmm_run's pipeline full.
+//   head  sampler parameters of (r, w) -> LDS, exact culling of the obstacle table;
+//   body  gmm_body;
+//   tail  the task's rows -> ONE write-through partial row (r, slot) -> every storing wave drains ->
+//         the block meets -> ticket (r, w); the block that draws the last one acquires, adds the
+//         run's partial rows and (one GPU) advances the mixture to the next waypoint.
+template <int K, bool STORE, int TB>
+__global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_step(pocs_gmm_launch a) {
+  typedef gmm_smem<K, TB, 1> smem_t;
+  constexpr int NC = smem_t::NC, RB = smem_t::RB;
+  __shared__ smem_t sm;
+  const int tid = threadIdx.x;
+  const int w = a.waypoint, r = blockIdx.y, slot = blockIdx.x;
+  gmm_stage_static(a, sm);
+  for (int j = tid; j < K * POCS_PARAM_STRIDE; j += TB)
+    sm.par[0][j] = load_wt(&a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j]);
+  __syncthreads();
+  if (tid < 64) gmm_cull(a, sm, 0, tid);
+  __syncthreads();
+  long long c_begin, c_end;
+  gmm_slice_chunks(a, slot, &c_begin, &c_end);
+  c_begin = uniform64(c_begin); c_end = uniform64(c_end);      // (64-bit division runs on the vector unit)
+#if defined(POCS_TASK_STAMPS)
+  unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
+  gmm_body<K, STORE, false, TB>(a, &sm.tab, sm.par[0], sm.keep[0], __builtin_amdgcn_readfirstlane(sm.nkeep[0]), sm.red[0], w, r,
+                                a.hdr[r].seed, c_begin, c_end, st_, last_);
+#else
+  gmm_body<K, STORE, false, TB>(a, &sm.tab, sm.par[0], sm.keep[0], __builtin_amdgcn_readfirstlane(sm.nkeep[0]), sm.red[0], w, r,
+                                a.hdr[r].seed, c_begin, c_end);
+#endif
+  __syncthreads();
+  if (tid < NC) store_wt(&a.partial[((size_t)r * a.slices + slot) * NC + tid], gmm_row_total<NC, RB>(sm.red[0], tid));
   drain_stores();
   __syncthreads();
-  POCS_STAMP(4);
   if (tid == 0) {
     const unsigned t = __hip_atomic_fetch_add(&a.ticket[(size_t)r * a.W + w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t == (unsigned)a.slices - 1u) ? 1 : 0;
@@ -622,87 +662,80 @@ __device__ __forceinline__ bool gmm_task(const pocs_gmm_launch& a, gmm_smem<K, T
     sm.last = last;
   }
   __syncthreads();
-  POCS_STAMP(5);
-  return __builtin_amdgcn_readfirstlane(sm.last) != 0;
-}
-
-// The block that drew the last ticket of (r, w): the a.slices partial rows of the run, read back past
-// L1 and added in a fixed order (slice q of column c sums rows q, q+S, q+2S, ...; then slices in
-// order) -> moments[w][r]; with `advance`, the mixture of waypoint w+1 right away (these ARE the
-// global moments on one GPU) -- and, with `publish`, ready[r] = w + 1 for the tasks waiting for it.
-template <int K, int TB>
-__device__ __forceinline__ void gmm_finish(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm, const int w, const int r,
-                                           const bool advance, const bool publish) {
-  constexpr int NC = K * POCS_NMOM;
-  constexpr int S = TB / NC;
-  const int tid = threadIdx.x;
-  const int q = tid / NC, c = tid - q * NC;
-  double v = 0.0;
-  if (q < S) {
-    const int nb = a.slices;
-    for (int b = q; b < nb; b += 8 * S) {        // 8 loads in flight, added in row order
-      double rows[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int bb = b + u * S;
-        rows[u] = (bb < nb) ? load_wt(&a.partial[((size_t)r * nb + bb) * NC + c]) : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v += rows[u];
-    }
-  }
-  sm.part[tid] = v;
-  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(sm.last) == 0) return;
   double* const l_mom = advance_ptrs(a, K, w + 1, r, sm.adv).l_mom;
-  if (tid < NC) {
-    double tot = sm.part[tid];
-    for (int sl = 1; sl < S; ++sl) tot += sm.part[sl * NC + tid];
-    a.moments[((size_t)w * a.nruns + r) * NC + tid] = tot;
-    l_mom[tid] = tot;
-  }
-  if (advance) {
-    advance_block(a, K, w + 1, r, sm.adv, sm.spec, true, tid, TB);       // starts with a barrier after staging
-    if (publish && tid == 0)                                              // wave 0 has drained its state / param stores
-      __hip_atomic_store(&a.sync[POCS_SYNC_READY + r], (unsigned)(w + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// One waypoint as its own launch: grid = (slices, runs), block (j, r) = task (a.waypoint, r, j).  The
-// per-waypoint path of a caller that exchanges the moments between waypoints (sharded over GPUs).
-template <int K, bool STORE, int TB>
-__global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_step(pocs_gmm_launch a) {
-  __shared__ gmm_smem<K, TB> sm;
-  gmm_stage_static(a, sm);
-  const int w = a.waypoint, r = blockIdx.y;
-#if defined(POCS_TASK_STAMPS)
-  unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long last_ = 0;
-#endif
-  gmm_stage_task<K, TB>(a, sm, 0, w, r);
-  if (gmm_task<K, STORE, false, TB>(a, sm, w, r, (int)blockIdx.x, 0 POCS_STAMP_PASS))     // a launch of its own per waypoint: streaming stores
-    gmm_finish<K, TB>(a, sm, w, r, a.advance_in_tail != 0, false);
+  gmm_close_sums<K, RB>(a, w, r, sm.par[0], &sm.red[0][0][0], l_mom, tid, TB, [] { __syncthreads(); });
+  if (a.advance_in_tail) advance_block(a, K, w + 1, r, sm.adv, sm.spec, true, tid, TB);     // starts with a barrier after staging
 }
 
 // ---------------------------------------------------------------------------------------------
 // The whole run in ONE launch: every task (w, r, j) of the call's W waypoints x R runs x S slices,
-// handed out in that order from a queue (one returning atomic per task).  A task of waypoint w > 0
-// waits for `ready[r] >= w`, published by the block that closed (r, w-1) -- a task handed out earlier
-// to a block that is running, so the wait always ends, however many blocks are resident.  Nothing
-// synchronises the grid: while the last arriver of a run reduces and advances its mixture, the other
-// blocks are already on tasks of other runs (R * S is ~1.5 x the resident blocks), and the next
-// waypoint's tasks of this run find their parameters published when their turn comes.  Every wait is
-// bounded (2 s): a block that gives up sets the call's abort word and every block leaves at its next
-// dequeue; the host reports POCS_E_DEVICE.
+// handed out in that order from a queue (one returning atomic per task and block).  A task of
+// waypoint w > 0 needs `ready[r] >= w`, published by whoever closed (r, w-1) -- a task handed out
+// earlier to a block that is running, so the wait always ends, however many blocks are resident.
+//
+// Nothing synchronises the grid, and nothing synchronises a block either: its waves run the block's
+// tasks one after the other, each at its own pace, through a small pipeline kept in LDS.
+//   * One wave is the LOADER of task n+1 (wave (n+1) mod 8: the role goes round): at the start of its
+//     share of task n (when it has no sample stores in flight: a wave's loads, atomics and stores
+//     complete in issue order, and write-through stores are slow to complete) it takes task n+1 from
+//     the queue and, if that task's parameters are published, stages them and the culled obstacle
+//     table into buffer (n+1) % 3; otherwise it tries again, and then waits, after its share of the
+//     body.  seq[b] = n+2 hands the buffer to the other waves, who wait for it in LDS only.
+//   * A wave that has sampled its share of task n and drained its stores counts itself in done[b].
+//     The wave that counts last CLOSES the task for the block: rows -> the task's write-through
+//     partial row -> drain -> ticket (r, w).  The wave that draws the run's last ticket acquires,
+//     adds the run's partial rows, advances the mixture of run r to waypoint w+1 (one wave:
+//     advance_wave) and publishes ready[r] = w+1 -- while its block's other waves and every other
+//     block are already sampling.  freed[b] = n+1 gives the buffer back to wave 0.
+// With R * S ~ 2.2 x the resident blocks per waypoint the tasks of waypoint w+1 come up in the queue
+// when those of waypoint w have long been closed: the loader finds them published, and a block goes
+// from one body straight into the next.  Every wait is bounded (2 s): a wave that gives up sets the
+// call's give-up word and the block's quit word, everybody leaves at the next look, and the host
+// reports POCS_E_DEVICE.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool wait_ready(unsigned* ready, unsigned need, unsigned* abort_word) {
+// task buffers of k_gmm_run: three while two blocks of them fit a CU's 160 KB of LDS (K <= 5), two beyond
+#define POCS_RUN_NB_OF(K) ((K) <= 5 ? 3 : 2)
+__device__ __forceinline__ unsigned lds_load(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// LDS words written by another wave of the block: order our LDS accesses around them
+__device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+// Spin (whole wave, uniform) until *word == want, in LDS.  false: the block is quitting.
+__device__ __forceinline__ bool wait_lds(const unsigned* word, const unsigned want, unsigned* quit, unsigned* abort_word) {
   const unsigned long long t0 = wall_clock64();                         // 100 MHz
+  unsigned polls = 0;
+  while (lds_load(word) != want) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++polls & 63u) == 0u) {
+      if (lds_load(quit) != 0u) return false;
+      if (wall_clock64() - t0 > 200000000ull) {                         // 2 s
+        __hip_atomic_store(abort_word, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_store(quit, 1u);
+        return false;
+      }
+    }
+  }
+  lds_acquire();
+  return true;
+}
+// ... until ready[r] >= need, in global memory (one lane polls; the caller acquires afterwards).
+__device__ __forceinline__ bool wait_ready(unsigned* ready, const unsigned need, unsigned* quit, unsigned* abort_word) {
+  const unsigned long long t0 = wall_clock64();
   unsigned polls = 0;
   while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
     __builtin_amdgcn_s_sleep(4);
-    if ((++polls & 255u) == 0u) {
-      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-      if (wall_clock64() - t0 > 200000000ull) {                         // 2 s
+    if ((++polls & 63u) == 0u) {
+      if (lds_load(quit) != 0u) return false;
+      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+          wall_clock64() - t0 > 200000000ull) {
         __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_store(quit, 1u);
         return false;
       }
     }
@@ -710,72 +743,197 @@ __device__ __forceinline__ bool wait_ready(unsigned* ready, unsigned need, unsig
   return true;
 }
 
-template <int K, bool STORE, int TB>
-__global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_run(pocs_gmm_launch a) {
-  __shared__ gmm_smem<K, TB> sm;
-  gmm_stage_static(a, sm);
-  const int tid = threadIdx.x;
+// The loader wave of task `next` (= n + 1), all 64 lanes: stage it.  pending = the queue number
+// already drawn for it (0xfffffffe: none yet).  blocking = wait for the buffer and for the task's
+// parameters if need be.  Returns true when the task is staged and handed over (or the queue is
+// exhausted: task_id >= total tells everybody to leave).
+template <int K, int TB, int NB>
+__device__ __forceinline__ bool gmm_stage_next(const pocs_gmm_launch& a, gmm_smem<K, TB, NB>& sm, const unsigned next,
+                                               unsigned& pending, const bool blocking, const int lane) {
   const unsigned per_wp = (unsigned)a.nruns * (unsigned)a.slices;
   const unsigned total = per_wp * (unsigned)a.W;
+  const int b = (int)(next % (unsigned)NB);
+  if (next >= (unsigned)NB) {                        // the buffer's previous task (next - NB) must be closed
+    const unsigned want = next - (unsigned)NB + 1u;
+    if (lds_load(&sm.freed[b]) != want) {
+#if defined(POCS_TASK_STAMPS)
+      if (lane == 0) atomicAdd(&g_stamps[blocking ? 11 : 10], 1ull);
+#endif
+      if (!blocking) return false;
+      if (!wait_lds(&sm.freed[b], want, &sm.quit, &a.sync[POCS_SYNC_ABORT])) return false;
+    }
+    lds_acquire();
+  }
+  if (pending == 0xfffffffeu) {
+    unsigned t = 0u;
+    if (lane == 0) {
+      t = __hip_atomic_fetch_add(&a.sync[POCS_SYNC_HEAD], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) t = 0xffffffffu;
+    }
+    pending = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+  }
+  const unsigned t = pending;
+  if (t < total) {
+    const int w = __builtin_amdgcn_readfirstlane((int)(t / per_wp));
+    const int r = __builtin_amdgcn_readfirstlane((int)((t - (unsigned)w * per_wp) / (unsigned)a.slices));
+    if (w > 0) {
+      unsigned have = 0u;
+      if (lane == 0) have = __hip_atomic_load(&a.sync[POCS_SYNC_READY + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)have) < (unsigned)w) {
+#if defined(POCS_TASK_STAMPS)
+        if (lane == 0) atomicAdd(&g_stamps[blocking ? 15 : 14], 1ull);
+#endif
+        if (!blocking) return false;
+        if (!wait_ready(&a.sync[POCS_SYNC_READY + r], (unsigned)w, &sm.quit, &a.sync[POCS_SYNC_ABORT])) return false;
+      }
+      acquire_agent();                               // the poll matched: ONE acquire, then the loads
+    }
+    const int slot = (int)(t - (unsigned)w * per_wp) - r * a.slices;
+    stage_batched<2>(sm.par[b], K * POCS_PARAM_STRIDE, lane, 64, [&](int j) -> double {
+      return load_wt(&a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j]); });
+    if (lane == 0) {
+      long long cb, ce;
+      gmm_slice_chunks(a, slot, &cb, &ce);
+      sm.seed[b] = a.hdr[r].seed;
+      sm.c_begin[b] = cb; sm.c_end[b] = ce;
+      sm.tw[b] = w; sm.tr[b] = r; sm.tslot[b] = slot;
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    gmm_cull(a, sm, b, lane);
+  }
+  if (lane == 0) {
+    sm.done[b] = 0u;
+    sm.task_id[b] = t;
+  }
+  lds_release();
+  if (lane == 0) lds_store(&sm.seq[b], next + 1u);
+  pending = 0xfffffffeu;
+  return true;
+}
+
+template <int K, bool STORE, int TB>
+__global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_run(pocs_gmm_launch a) {
+  constexpr int NB = POCS_RUN_NB_OF(K);
+  typedef gmm_smem<K, TB, NB> smem_t;
+  constexpr int NC = smem_t::NC, RB = smem_t::RB, NW = TB / 64;
+  __shared__ smem_t sm;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned per_wp = (unsigned)a.nruns * (unsigned)a.slices;
+  const unsigned total = per_wp * (unsigned)a.W;
+  gmm_stage_static(a, sm);
+  if (tid < NB) { sm.seq[tid] = 0u; sm.done[tid] = 0u; sm.freed[tid] = 0u; sm.task_id[tid] = 0u; }
+  if (tid == 0) { sm.lock = 0u; sm.quit = 0u; }
+  __syncthreads();                                   // the only barrier of the launch
+  unsigned pending = 0xfffffffeu;
+  if (wave == 0 && !gmm_stage_next(a, sm, 0u, pending, true, lane)) return;
 #if defined(POCS_TASK_STAMPS)
   unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = wall_clock64();
   const unsigned long long t_begin_ = last_;
 #endif
-  if (tid == 0) {                                                       // the block's first task
-    unsigned t = __hip_atomic_fetch_add(&a.sync[POCS_SYNC_HEAD], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) t = 0xffffffffu;
-    sm.next_task = t;
-    sm.next_state = 1u;
-  }
-  __syncthreads();
-  int buf = 0;
-  for (;;) {
-    const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)sm.next_task);     // block-uniform, and provably so
-    const unsigned state = (unsigned)__builtin_amdgcn_readfirstlane((int)sm.next_state);
+  for (unsigned n = 0;; ++n) {
+    const int b = (int)(n % (unsigned)NB);
+    // the loader of task n + 1 is wave (n + 1) mod NW: the role goes round, so that its round trips (and
+    // the closing of a task, which falls to whichever wave finishes last) delay every wave alike
+    const bool loader = wave == (int)((n + 1u) % (unsigned)NW);
+    if (!wait_lds(&sm.seq[b], n + 1u, &sm.quit, &a.sync[POCS_SYNC_ABORT])) break;
+    POCS_STAMP(0);
+    const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)sm.task_id[b]);
     if (t >= total) break;
-    // (integer division runs on the vector unit: pin the quotients back into scalar registers)
-    const int w = __builtin_amdgcn_readfirstlane((int)(t / per_wp));
-    const unsigned rem = t - (unsigned)w * per_wp;
-    const int r = __builtin_amdgcn_readfirstlane((int)(rem / (unsigned)a.slices));
-    const int slot = (int)rem - r * a.slices;
+    const int w = __builtin_amdgcn_readfirstlane(sm.tw[b]), r = __builtin_amdgcn_readfirstlane(sm.tr[b]);
+    const int slot = __builtin_amdgcn_readfirstlane(sm.tslot[b]);
+    const uint64_t seed = (uint64_t)uniform64((long long)sm.seed[b]);
+    const long long c_begin = uniform64(sm.c_begin[b]), c_end = uniform64(sm.c_end[b]);
+    bool staged = true;
+    if (loader) staged = gmm_stage_next(a, sm, n + 1u, pending, false, lane);
+    POCS_STAMP(1);
 #if defined(POCS_TASK_STAMPS)
-    if (tid == 0 && state == 2u) st_[10] += 1;
-    POCS_STAMP(7);                                                      // loop-end barrier + decode
+    gmm_body<K, STORE, true, TB>(a, &sm.tab, sm.par[b], sm.keep[b], __builtin_amdgcn_readfirstlane(sm.nkeep[b]), sm.red[b], w, r,
+                                 seed, c_begin, c_end, st_, last_);
+#else
+    gmm_body<K, STORE, true, TB>(a, &sm.tab, sm.par[b], sm.keep[b], __builtin_amdgcn_readfirstlane(sm.nkeep[b]), sm.red[b], w, r,
+                                 seed, c_begin, c_end);
 #endif
-    if (state != 2u) {                                                  // not staged by the prefetch: wait, then stage
-      if (w > 0) {
-        if (tid == 0) {
-          const unsigned go = wait_ready(&a.sync[POCS_SYNC_READY + r], (unsigned)w, &a.sync[POCS_SYNC_ABORT]) ? 1u : 0u;
-          if (go) acquire_agent();
-          sm.go = go;
+    // this wave's share is sampled: drain its stores, count it in
+    drain_stores();
+    POCS_STAMP(5);
+    lds_release();
+    unsigned pos = 0u;
+    if (lane == 0) pos = __hip_atomic_fetch_add(&sm.done[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)pos) == (unsigned)NW - 1u) {
+    // ---- the block's last wave for this task closes it
+    lds_acquire();
+    for (int c = lane; c < NC; c += 64)
+      store_wt(&a.partial[((size_t)r * a.slices + slot) * NC + c], gmm_row_total<NC, RB>(sm.red[b], c));
+    drain_stores();
+    unsigned tk = 0u;
+    if (lane == 0) tk = __hip_atomic_fetch_add(&a.ticket[(size_t)r * a.W + w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)tk) == (unsigned)a.slices - 1u) {
+      // ---- ... and the run's last block for this waypoint closes (r, w)
+#if defined(POCS_TASK_STAMPS)
+      const unsigned long long f0_ = wall_clock64();
+#endif
+      acquire_agent();
+      bool mine = true;                              // the advance scratch is one wave's at a time
+      {
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+          unsigned old = 1u;
+          if (lane == 0) { unsigned exp = 0u; old = __hip_atomic_compare_exchange_strong(&sm.lock, &exp, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 0u : 1u; }
+          if (__builtin_amdgcn_readfirstlane((int)old) == 0) break;
+          __builtin_amdgcn_s_sleep(2);
+          if (lds_load(&sm.quit) != 0u || wall_clock64() - t0 > 200000000ull) { mine = false; break; }
         }
-        __syncthreads();
-        if (__builtin_amdgcn_readfirstlane((int)sm.go) == 0) break;
+      }
+      if (!mine) {
+        __hip_atomic_store(&a.sync[POCS_SYNC_ABORT], 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_store(&sm.quit, 1u);
+        break;
+      }
+      lds_acquire();
+#if defined(POCS_TASK_STAMPS)
+      const unsigned long long f1_ = wall_clock64();
+#endif
+      double* const l_mom = advance_ptrs(a, K, w + 1, r, sm.adv).l_mom;
+      gmm_close_sums<K, RB>(a, w, r, sm.par[b], &sm.red[b][0][0], l_mom, lane, 64,
+                            [] { __threadfence_block(); __builtin_amdgcn_wave_barrier(); });
+#if defined(POCS_TASK_STAMPS)
+      const unsigned long long f2_ = wall_clock64();
+#endif
+      if (w + 1 < a.W) {
+        advance_wave(a, K, w + 1, r, sm.adv, lane);                    // ends with its stores drained
+        if (lane == 0)
+          __hip_atomic_store(&a.sync[POCS_SYNC_READY + r], (unsigned)(w + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #if defined(POCS_TASK_STAMPS)
-      POCS_STAMP(11);                                                   // wait for `ready` + acquire
+      if (lane == 0) {
+        const unsigned long long f3_ = wall_clock64();
+        atomicAdd(&g_stamps[16], f1_ - f0_); atomicAdd(&g_stamps[17], f2_ - f1_); atomicAdd(&g_stamps[18], f3_ - f2_);
+        atomicAdd(&g_stamps[19], 1ull);
+      }
 #endif
-      gmm_stage_task<K, TB>(a, sm, buf, w, r);
+      lds_release();
+      if (lane == 0) lds_store(&sm.lock, 0u);
     }
-    POCS_STAMP(0);
-    if (gmm_task<K, STORE, true, TB>(a, sm, w, r, slot, buf POCS_STAMP_PASS)) {
-      gmm_finish<K, TB>(a, sm, w, r, w + 1 < a.W, true);
-      POCS_STAMP(6);
-#if defined(POCS_TASK_STAMPS)
-      if (tid == 0) st_[8] += 1;
-#endif
+    lds_release();
+    if (lane == 0) lds_store(&sm.freed[b], n + 1u);
     }
-    __syncthreads();
+    POCS_STAMP(6);
+    // the loader could not stage the next task before its share of this one (not published yet, or the
+    // buffer still in use): now it waits -- AFTER counting itself in above, the closing of this very
+    // task may be what the next one is waiting for
+    if (loader && !staged && !gmm_stage_next(a, sm, n + 1u, pending, true, lane)) break;
+    POCS_STAMP(7);
 #if defined(POCS_TASK_STAMPS)
-    if (tid == 0) st_[9] += 1;
+    st_[9] += 1;
 #endif
-    buf ^= 1;
   }
 #if defined(POCS_TASK_STAMPS)
-  if (tid == 0) {
+  if (lane == 0) {
     const unsigned long long life_ = wall_clock64() - t_begin_;
-    for (int i = 0; i < 12; ++i) atomicAdd(&g_stamps[i], st_[i]);
+    for (int i = 0; i < 10; ++i) atomicAdd(&g_stamps[i], st_[i]);
     atomicAdd(&g_stamps[12], life_);
     atomicAdd(&g_stamps[13], 1ull);
   }
@@ -947,18 +1105,20 @@ hipError_t pocs_launch_gmm_step(int K, const pocs_gmm_launch& a, hipStream_t s) 
 #if defined(POCS_TASK_STAMPS)
 static hipError_t launch_gmm_run_plain(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);
 hipError_t pocs_launch_gmm_run(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s) {
-  unsigned long long z[16] = {0};
+  unsigned long long z[32] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
   const hipError_t e = launch_gmm_run_plain(K, nblk, a, s);
   (void)hipStreamSynchronize(s);
-  unsigned long long h[16];
+  unsigned long long h[32];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) == hipSuccess && h[13] > 0) {
-    static const char* names[7] = {"stage", "head", "body", "flush", "partial+drain", "ticket", "finish"};
-    const double nb = (double)h[13], tasks = (double)h[9];
-    fprintf(stderr, "stamps: %g blocks, %g tasks (%g finishes, %.0f %% prefetched), mean block lifetime %.1f us; per task (us): loop-end %.2f wait+acquire %.2f",
-            nb, tasks, (double)h[8], 100.0 * (double)h[10] / tasks, 0.01 * h[12] / nb, 0.01 * (double)h[7] / tasks, 0.01 * (double)h[11] / tasks);
-    for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.2f", names[i], 0.01 * (double)h[i] / tasks);
-    fprintf(stderr, "; per finish: %.2f us\n", h[8] ? 0.01 * (double)h[6] / (double)h[8] : 0.0);
+    static const char* names[8] = {"wait-seq", "decode+stage-try", "prologue", "loop", "flush", "drain", "count+close", "stage-blocking"};
+    const double nw = (double)h[13], tasks = (double)h[9];
+    fprintf(stderr, "stamps: %g waves, %g wave-tasks, mean wave lifetime %.1f us; per wave-task (us):", nw, tasks, 0.01 * h[12] / nw);
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.2f", names[i], 0.01 * (double)h[i] / tasks);
+    fprintf(stderr, "; of %g tasks the loader found: buffer busy %llu (again when blocking %llu), not published %llu (again %llu)\n",
+            tasks / 8.0, h[10], h[11], h[14], h[15]);
+    if (h[19]) fprintf(stderr, "stamps: %llu run-waypoints closed; per closing (us): acquire+lock %.2f, adding the rows %.2f, advance+publish %.2f\n", h[19],
+                       0.01 * (double)h[16] / (double)h[19], 0.01 * (double)h[17] / (double)h[19], 0.01 * (double)h[18] / (double)h[19]);
   }
   return e;
 }

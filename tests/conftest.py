@@ -6,14 +6,6 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-import os
-
-# The library runs a call as ONE queue-driven launch (k_gmm_run) from 16 runs per call and as one launch
-# per waypoint below that -- a speed heuristic, the results are bitwise the same.  The suite wants the
-# queue-driven kernel exercised at EVERY batch size (the per-waypoint form is compared with it wherever
-# POCS_OPT_PERSISTENT is switched off); the threshold is read once per process.
-os.environ.setdefault("POCS_PERSISTENT_MIN_RUNS", "1")
-
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "oracle"))

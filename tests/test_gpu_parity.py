@@ -177,15 +177,15 @@ def test_gmm_one_million_samples_within_1e6(ctx, orc, plan, env):
 
 
 def test_gmm_variants_agree(ctx, pocs, plan, env):
-    """The whole run in one launch (k_gmm_run, the default) vs one launch per waypoint (k_gmm_step),
-    graph replay vs eager launches, with and without the sample store, and the per-waypoint step
-    API: the same tasks with the same arithmetic, so everything is bitwise the same."""
+    """One launch per waypoint (k_gmm_step, the default) vs the whole run in one queue-driven launch
+    (k_gmm_run), graph replay vs eager launches, with and without the sample store, and the
+    per-waypoint step API: the same tasks with the same arithmetic, so everything is bitwise the same."""
     ctx.configure(plan, env, K=3, N=20000, seed=11)
     base = ctx.run_gmm_estimation()
     base_probs = ctx.waypoint_probabilities().copy()
     base_m = ctx.moments(30, 3).copy()
     base_xyz, base_flags = ctx.gmm_samples(20000)
-    for opt, val in ((pocs.OPT_USE_GRAPH, 0), (pocs.OPT_STORE_SAMPLES, 0), (pocs.OPT_PROFILE, 1), (pocs.OPT_PERSISTENT, 0)):
+    for opt, val in ((pocs.OPT_USE_GRAPH, 0), (pocs.OPT_STORE_SAMPLES, 0), (pocs.OPT_PROFILE, 1), (pocs.OPT_PERSISTENT, 1)):
         ctx.set_option(opt, val)
         ctx.set_seed(11)
         assert ctx.run_gmm_estimation() == base
@@ -193,14 +193,14 @@ def test_gmm_variants_agree(ctx, pocs, plan, env):
         assert np.array_equal(ctx.moments(30, 3), base_m)        # fixed-shape reduction: bitwise
         if opt == pocs.OPT_PROFILE:
             ms, n = ctx.kernel_time()
-            assert n == 1 and ms > 0                             # ONE launch covers the 56 waypoints
+            assert n == 56 and ms > 0                            # one launch per waypoint
         if opt == pocs.OPT_PERSISTENT:
             xyz, flags = ctx.gmm_samples(20000)
             assert np.array_equal(xyz, base_xyz) and np.array_equal(flags, base_flags)
             ctx.set_option(pocs.OPT_PROFILE, 1)
             ctx.set_seed(11)
             assert ctx.run_gmm_estimation() == base
-            assert ctx.kernel_time()[1] == 56                    # one launch per waypoint
+            assert ctx.kernel_time()[1] == 1                     # ONE launch covers the 56 waypoints
             ctx.set_option(pocs.OPT_PROFILE, 0)
         ctx.set_option(opt, 1 - val)
     ctx.set_seed(11)
@@ -223,8 +223,7 @@ def test_persistent_kernel_under_uneven_load(pocs, plan, env, K, N, R):
     with pocs.Context(0) as c:
         c.configure(plan, env, K=K, N=N, seed=123)
         c.set_batch(R)
-        c.set_option(pocs.OPT_PERSISTENT, 0)
-        c.run_gmm_estimation()
+        c.run_gmm_estimation()                                  # one launch per waypoint (the default)
         want_p = list(c.batch_probabilities())
         want_m = np.array([c.moments(w, K) for w in range(56)])
         want_s = c.gmm_state_raw(55, K).copy()

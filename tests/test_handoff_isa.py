@@ -67,9 +67,9 @@ def test_gmm_kernel_handoff_shapes(listing, sub, streaming_bits):
     handed = [o for o in stores if o.startswith("global_store_dwordx2")]
     plain = [o for o in handed if "sc1" not in o.split()]
     assert len(handed) >= 4 and len(plain) == 1, handed               # the one plain store: moments[w][r]
-    # L1-bypassing loads of partial rows / params / state
+    # L1-bypassing loads of partial rows / params / state (at least one site each)
     loads_sc1 = [o for o in mem_ops(ops, "global_load_dwordx2") if "sc1" in o.split()]
-    assert len(loads_sc1) >= 9, loads_sc1
+    assert len(loads_sc1) >= 3, loads_sc1
     assert not mem_ops(ops, "flat_"), "flat accesses in a GMM kernel"
     # the consumer's acquire: buffer_inv sc1, waited for before the next barrier
     inv = [i for i, o in enumerate(ops) if o.startswith("buffer_inv") and "sc1" in o.split()]
@@ -77,20 +77,22 @@ def test_gmm_kernel_handoff_shapes(listing, sub, streaming_bits):
     for i in inv:
         nxt = next(j for j in range(i + 1, len(ops)) if ops[j].startswith(("s_barrier", "s_endpgm")))
         assert any(o.startswith("s_waitcnt") and "vmcnt(0)" in o for o in ops[i + 1:nxt]), (sub, i)
-    # the ticket: a returning agent-scope add, behind a drain and a barrier
+    # the ticket: a returning agent-scope add behind the drain of the partial row's stores -- and, in
+    # k_gmm_step, behind the barrier at which every wave has drained (in k_gmm_run ONE wave stores and signals)
     atom = [i for i, o in enumerate(ops) if o.startswith("global_atomic_add")]
     assert atom, "no ticket atomic"
     seen = 0
     for i in atom:
-        prev_bar = max((j for j in range(i) if ops[j].startswith("s_barrier")), default=None)
-        if prev_bar is None:
-            continue                                                   # the queue's first dequeue: nothing stored yet
-        prev_store = max((j for j in range(prev_bar) if ops[j].startswith("global_store")), default=None)
+        prev_store = max((j for j in range(i) if ops[j].startswith("global_store_dwordx2") and "sc1" in ops[j].split()), default=None)
         if prev_store is None:
+            continue                                                   # the queue's dequeue ahead of any store
+        between = ops[prev_store + 1:i]
+        if not any(o.startswith("s_waitcnt") and "vmcnt(0)" in o for o in between):
             continue
-        if any(o.startswith("s_waitcnt") and "vmcnt(0)" in o for o in ops[prev_store + 1:prev_bar + 1]):
-            seen += 1
-    assert seen >= 1, "no store -> s_waitcnt vmcnt(0) -> s_barrier -> atomic sequence in " + sub
+        if "k_gmm_step" in sub and not any(o.startswith("s_barrier") for o in between):
+            continue
+        seen += 1
+    assert seen >= 1, "no sc1 store -> s_waitcnt vmcnt(0) [-> s_barrier] -> atomic sequence in " + sub
 
 
 def test_advance_kernel_publishes_write_through(listing):

@@ -1,11 +1,11 @@
 #!/bin/bash
-# A/B sweep of bench.py on one GPU: the persistent kernel (k_gmm_run) against one launch per waypoint
-# (POCS_PERSISTENT=0), at the driver's invocation (--steps 20 --warmup 5), the default (256 / 64) and
-# one run per call.  usage: tools/bench_sweep.sh out.txt [extra env assignments...]
+# A/B sweep of bench.py on one GPU: one launch per waypoint (k_gmm_step, the default) against the
+# queue-driven kernel (POCS_PERSISTENT=1, k_gmm_run), at the driver's invocation (--steps 20 --warmup 5),
+# the default (256 / 64) and small batches.  usage: tools/bench_sweep.sh out.txt
 out=${1:-gpurun_out/sweep.txt}; shift
 : > "$out"
 run() { echo "## $*" >> "$out"; env "$@" >> "$out" 2>> "$out.err" || echo "FAILED: $*" >> "$out"; }
-for pers in 1 0; do
+for pers in 0 1; do
   run POCS_PERSISTENT=$pers python bench.py --steps 20 --warmup 5 --no-cpu-baseline
   run POCS_PERSISTENT=$pers python bench.py --steps 256 --warmup 64 --no-cpu-baseline
   run POCS_PERSISTENT=$pers python bench.py --batch 1 --steps 16 --warmup 4 --no-cpu-baseline

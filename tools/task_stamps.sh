@@ -1,7 +1,7 @@
 #!/bin/bash
-# Diagnostic build of libpocs.so with per-task phase stamps in k_gmm_run (-DPOCS_TASK_STAMPS): where a
-# block spends its time (dequeue + wait for `ready`, head, body, flush, partial row + drain, ticket,
-# finish).  Never timed as a product build.  Build here, run on the GPU box with
+# Diagnostic build of libpocs.so with per-wave phase stamps in k_gmm_run (-DPOCS_TASK_STAMPS): where a
+# wave spends its time per task (wait for the staged task, decode + loader attempt, body prologue, sampling
+# loop, flush, drain, count-in + closing, blocking staging).  Never timed as a product build.  Run with
 #   POCS_LIB=ablate_build/libpocs_stamps.so POCS_NO_GRAPH=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline
 set -e
 cd "$(dirname "$0")/.."
