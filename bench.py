@@ -9,8 +9,10 @@ remainder).  Default workload at --gpus 1 is BASELINE.json configs[1]: the bundl
 trajectory.dat / odometry.dat plan (56 waypoints), 10^6 samples, 3-component mixture.
 
 With --gpus G (launched by torch.distributed.run, one rank per GPU) every rank evaluates its own
-10^6 samples of a G x 10^6-sample mixture (weak scaling); per waypoint the moments of the whole
-batch (batch x 11 K doubles) are summed over ranks with ONE RCCL all-reduce.
+10^6 samples of a G x 10^6-sample mixture (weak scaling, the default) or its 1/G of the workload's
+samples (--scaling strong: BASELINE.json configs[3] = `--workload cfg3 --scaling strong --gpus 8`);
+per waypoint the moments of the whole batch (batch x 11 K doubles) are summed over ranks with ONE
+RCCL all-reduce.
 
 Prints ONE JSON line on rank 0 (fields: DESIGN.md section 7).
 """
@@ -100,6 +102,9 @@ def main():
                          "~15 us -- is paid once per waypoint for the whole batch), 8 for MC (8 x 28 MB of particle "
                          "state stay in the 256 MB Infinity Cache between waypoint launches, 16 x do not)")
     ap.add_argument("--samples", type=int, default=0, help="override samples per GPU (experiments only)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's sample count PER GPU; strong: the workload's sample count in total, "
+                         "split evenly over the GPUs (cfg4 = cfg3 over 8 GPUs)")
     ap.add_argument("--mc-fused", action="store_true",
                     help="MC workloads: whole roll-out in registers (k_mc_fused, ~0 B/eval) instead of streaming")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,6 +142,8 @@ def main():
     W, n_local, K, path = WORKLOADS[args.workload]
     if args.samples:
         n_local = args.samples
+    if args.scaling == "strong":           # the same total workload over more GPUs (even shards: pairs of samples share draws)
+        n_local = max(2, (n_local // world) & ~1)
     plan = pocs_amd.load_plan()
     if W != 56:
         plan = pocs_amd.resample_plan(plan, W)
@@ -259,29 +266,64 @@ def main():
     # correction applied) are taken offline and committed with their source in profiles/traffic.json
     traffic, traffic_src = None, None
     tj = ROOT / "profiles" / "traffic.json"
-    if tj.exists() and not args.samples:
-        rec = json.loads(tj.read_text()).get("%s_batch%d" % (args.workload, batch))
-        if rec:
-            traffic, traffic_src = rec["bytes_per_launch"], rec["source"]
+    if tj.exists():
+        # the committed PMC record of this workload whose launch is nearest in size: its measured bytes
+        # per evaluation x the evaluations of THIS launch
+        recs = [(k, v) for k, v in json.loads(tj.read_text()).items()
+                if v.get("path", "gmm" if k.startswith("cfg") and not k.startswith("cfg5") else "mc") == path and v.get("evals_per_launch")]
+        if recs:
+            k, rec = min(recs, key=lambda kv: abs(kv[1]["evals_per_launch"] - units))
+            traffic = rec["bytes_per_launch"] / rec["evals_per_launch"] * units
+            traffic_src = "%.3f B/eval measured at %d evals per launch (%s) x %d evals" % (
+                rec["bytes_per_launch"] / rec["evals_per_launch"], rec["evals_per_launch"], rec["source"].split(":")[0], units)
     copy_gbps = ctx.copy_bandwidth(1 << 30)       # measured streaming-copy ceiling of this GPU, same process
-    roofline = {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "limiter": "FP64 VALU issue, not bandwidth: the SIMDs issue ~100 % of the time at ~210 vector instructions "
+                                           "per evaluation (profiles/r02_*_pmc.txt); the HBM fraction below is what that arithmetic reaches",
+                "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "copy_GBps": copy_gbps, "frac_of_copy": achieved / copy_gbps if copy_gbps > 0 else None,
                 "algorithmic_bytes_per_launch": bpe * units, "bytes_per_eval": bpe, "evals_per_launch": units,
                 "avg_kernel_us": avg_ms * 1e3,
                 "evals_per_s_in_kernel": units / (avg_ms * 1e-3) if avg_ms > 0 else 0.0}
 
+    # one run per call, no batch, no run-ahead: the rate of ONE runGMMEstimation / runSimulation command
+    # (SURVEY 8d defines the metric on one run* call; `value` above is the batched throughput)
+    single = None
+    if not sharded and os.environ.get("POCS_SKIP_SINGLE") != "1":
+        with pocs_amd.Context(local) as c1:
+            c1.configure(plan, env, K=K, N=N, seed=0x5EED0003)
+            c1.set_shard(0, n_local)
+            if args.mc_fused:
+                c1.set_option(pocs_amd.OPT_MC_FUSED, 1)
+            run1 = c1.run_gmm_estimation if path == "gmm" else c1.run_simulation
+            for _ in range(3):
+                run1()
+            torch.cuda.synchronize()
+            reps = 12
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                run1()
+            torch.cuda.synchronize()
+            single = float(n_local) * W * reps / (time.perf_counter() - t1)
+
     if rank == 0:
         out = {
             "metric": "particle-waypoint evals/s (GMM+collision)" if path == "gmm" else "particle-waypoint evals/s (MC+collision)",
             "value": value, "unit": "particle-waypoint evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "single_call_evals_per_s": single,
             "config": {"workload": "%s: %s path, %s plan (%d waypoints), %d samples per GPU per run, K=%d, pr2test2 walls, PR2 0.668 m square footprint"
                                    % (args.workload, path.upper(), "bundled trajectory.dat/odometry.dat" if W == 56 else "resampled", W, n_local, K),
                        "waypoints": W, "samples_per_gpu": n_local, "components": K, "probability": prob,
                        "runs_per_launch": batch, "calls": chunks,
-                       "engines_in_flight": len(engines) if engines else 1},
+                       "engines_in_flight": len(engines) if engines else 1,
+                       "total_samples_per_run": N,
+                       "value_is": "batched throughput: `runs_per_launch` independent runs (the reference driver's 200-run loop) "
+                                   "advance in lockstep per call; single_call_evals_per_s = one run per call",
+                       "sanity_band": "collision model = this build's 2-D boxes, not OpenRAVE/ODE + PR2 mesh (not in the reference tree): "
+                                      "200 runs at N = 10^4 give MC 0.706 / GMM 0.285 (profiles/r01_table1_like.txt) against the paper's "
+                                      "0.935 / 0.64; same ordering, different level -- parity unpinned at that call site (DESIGN.md 8)"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

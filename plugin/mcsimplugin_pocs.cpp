@@ -2,11 +2,19 @@
 // mcsimplugin/mcsimplugin.cpp): same interface name, same commands, estimator = libpocs.so.
 // NOT built in this repository's image (OpenRAVE and Boost are absent); build it where they are:
 //   g++ -shared -fPIC mcsimplugin_pocs.cpp $(openrave-config --cflags --libs-core) -I../include -lpocs
+//
+// What the reference's constructor does with `penv` (mcsimplugin.cpp:12 `sim(penv)` ->
+// MCSimulator.h:139-156: keep the environment and its first robot, to be asked
+// env->CheckCollision(robot) per pose, :257-285) happens here ONCE: the scene's box geometries become
+// the obstacle table of libpocs and the robot's base link its footprint.  The conversion itself is
+// csrc/scene_boxes.hpp, which has no OpenRAVE type in it and is compiled and tested in this
+// repository (tests/test_scene_boxes_cpp.py) on the geometries of the reference's scenes.
 #include <openrave/plugin.h>
 #include <boost/bind.hpp>
 #include <cstdlib>
 
 #include "../probability-of-collision-for-safe-planning_amd/csrc/mcmodule.hpp"
+#include "../probability-of-collision-for-safe-planning_amd/csrc/scene_boxes.hpp"
 
 using namespace OpenRAVE;
 
@@ -19,6 +27,7 @@ class MCModule : public ModuleBase {
         "setSeed", "setFootprint", "addObstacle", "clearObstacles", "setBatch", "setRunAhead"};
     for (const char* n : names)
       RegisterCommand(n, boost::bind(&MCModule::Forward, this, std::string(n), _1, _2), "see include/pocs.h");
+    HandOverScene(penv);
     // The reference driver issues one run* command per run, 200 in a row (MCSimulation.py:238-256):
     // evaluate them 16 at a time behind that interface (POCS_RUN_AHEAD overrides; 1 = off).
     const char* ra = getenv("POCS_RUN_AHEAD");
@@ -30,7 +39,54 @@ class MCModule : public ModuleBase {
     if (!impl_.SendCommand(sout, line)) { RAVELOG_ERROR("%s: %s\n", name.c_str(), impl_.last_error().c_str()); return false; }
     return true;
   }
+
  private:
+  // bodies -> links -> box geometries -> world transform + half extents (everything except the robot
+  // whose collisions are being estimated); the robot's base link -> footprint.  As MCSimulator's
+  // constructor, under the environment mutex (MCSimulator.h:150-152).
+  void HandOverScene(EnvironmentBasePtr penv) {
+    EnvironmentMutex::scoped_lock lock(penv->GetMutex());
+    std::vector<RobotBasePtr> robots;
+    penv->GetRobots(robots);
+    RobotBasePtr robot = robots.empty() ? RobotBasePtr() : robots[0];          // robots[0], MCSimulator.h:153-155
+    std::vector<KinBodyPtr> bodies;
+    penv->GetBodies(bodies);
+    std::vector<pocs::BoxGeom> geoms;
+    int other = 0;
+    for (KinBodyPtr body : bodies) {
+      if (robot && body == robot) continue;
+      for (KinBody::LinkPtr link : body->GetLinks()) {
+        const Transform Tl = link->GetTransform();
+        for (KinBody::Link::GeometryPtr geom : link->GetGeometries()) {
+          if (geom->GetType() != GT_Box) { ++other; continue; }                // meshes, cylinders: not representable
+          const TransformMatrix M(Tl * geom->GetTransform());
+          const Vector e = geom->GetBoxExtents();
+          pocs::BoxGeom g;
+          for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) g.R[3 * i + j] = M.m[4 * i + j];
+          g.t[0] = M.trans.x; g.t[1] = M.trans.y; g.t[2] = M.trans.z;
+          g.ext[0] = e.x; g.ext[1] = e.y; g.ext[2] = e.z;
+          g.name = body->GetName() + "/" + link->GetName();
+          geoms.push_back(g);
+        }
+      }
+    }
+    // the robot stands at z = 0.05 in the reference's scenes (pr2test2.env.xml:121) and is ~1.5 m tall
+    const pocs::SceneTable T = pocs::scene_to_table(geoms, 0.05, 1.5);
+    for (const std::string& s : T.skipped) RAVELOG_WARN("pocs: %s\n", s.c_str());
+    if (other) RAVELOG_WARN("pocs: %d non-box geometries are not part of the planar collision world\n", other);
+    if (pocs_set_obstacles(impl_.context(), T.boxes.empty() ? NULL : &T.boxes[0], T.M()) != POCS_OK)
+      throw openrave_exception(pocs_last_error(impl_.context()));
+    if (robot && !getenv("POCS_FOOTPRINT")) {                                  // "dx dy hx hy" overrides
+      const AABB ab = robot->GetLinks().at(0)->ComputeLocalAABB();
+      const double c[3] = {ab.pos.x, ab.pos.y, ab.pos.z}, h[3] = {ab.extents.x, ab.extents.y, ab.extents.z};
+      const pocs::Footprint f = pocs::footprint_from_aabb(c, h);
+      pocs_set_footprint(impl_.context(), f.dx, f.dy, f.hx, f.hy);
+    } else if (const char* fp = getenv("POCS_FOOTPRINT")) {
+      impl_.SendCommand(std::string("setFootprint ") + fp);
+    }
+    RAVELOG_INFO("pocs: collision world = %d boxes\n", T.M());
+  }
+
   pocs::MCModule impl_;
 };
 

@@ -51,7 +51,17 @@ def _compose(t_parent, yaw_parent, t_child, yaw_child):
              t_parent[2] + t_child[2]], yaw_parent + yaw_child)
 
 
-def load_env_xml(path, z_min=0.05, z_max=1.5, footprint=(0.0, 0.0, 0.334, 0.334)):
+def load_env_geoms(path):
+    """Every box geometry of the scene BEFORE the z filter, as the OpenRAVE adapter sees them
+    (link transform x geometry transform): list of (name, R row-major 9, t 3, half extents 3).
+    Feeds csrc/scene_boxes.hpp in tests/test_scene_boxes_cpp.py."""
+    geoms = []
+    env = load_env_xml(path, z_min=-1e300, z_max=1e300, _geoms=geoms)
+    assert len(geoms) == len(env["boxes"])
+    return geoms
+
+
+def load_env_xml(path, z_min=0.05, z_max=1.5, footprint=(0.0, 0.0, 0.334, 0.334), _geoms=None):
     """Returns dict(footprint, boxes M x 5 [cx cy hx hy yaw], skipped=[names], robot_start)."""
     root = ET.parse(str(path)).getroot()
     boxes, skipped = [], []
@@ -85,6 +95,10 @@ def load_env_xml(path, z_min=0.05, z_max=1.5, footprint=(0.0, 0.0, 0.334, 0.334)
                 if cz + ext[2] < z_min or cz - ext[2] > z_max:
                     continue                                  # floor, lintel, ...
                 boxes.append([cx, cy, ext[0], ext[1], yaw])
+                if _geoms is not None:
+                    c, s = math.cos(yaw), math.sin(yaw)
+                    _geoms.append(("%s/%s" % (name, body.get("name", "?")), [c, -s, 0.0, s, c, 0.0, 0.0, 0.0, 1.0],
+                                   [cx, cy, cz], list(ext)))
     start = None
     rob = root.find("Robot")
     if rob is not None:

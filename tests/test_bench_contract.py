@@ -32,9 +32,18 @@ def test_default_line_has_every_field():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert r["algorithmic_bytes_per_launch"] == 26 * r["evals_per_launch"]
+    assert r["traffic"] is not None and r["traffic"] > 0 and "B/eval measured" in r["traffic_source"]      # never null
+    assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    assert d["single_call_evals_per_s"] > 0 and "single_call" in d["config"]["value_is"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 0 and abs(d["value"] - 20000 * 56 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-9
+
+
+def test_strong_scaling_line():
+    """--scaling strong: the workload's samples in total (here: all of them on the one GPU)."""
+    d = run_bench("--scaling", "strong", "--no-cpu-baseline")
+    assert d["scaling"] == "strong" and d["config"]["total_samples_per_run"] == d["config"]["samples_per_gpu"] == 20000
 
 
 def test_mc_workload_line():

@@ -1,0 +1,65 @@
+"""The OpenRAVE adapter's scene hand-off (plugin/mcsimplugin_pocs.cpp -> csrc/scene_boxes.hpp): the
+reference module gets its collision world through its constructor (mcsimplugin.cpp:12,
+MCSimulator.h:139-156); the adapter walks the environment's bodies -> links -> box geometries and
+turns them into the obstacle table with the header tested here.  The header has no OpenRAVE type in
+it: this test compiles it (g++, no GPU) and feeds it the box geometries of the reference's scenes as
+3-D transforms, before any filtering; the table it produces must be the one envxml.py extracts and
+tests/test_env_scenes.py runs through the HIP path."""
+import math
+import subprocess
+from importlib import import_module
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+HERE = Path(__file__).resolve().parent
+REF = Path("/root/reference")
+
+
+@pytest.fixture(scope="module")
+def demo():
+    src, exe = HERE / "scene_boxes_demo.cpp", HERE / "_scene_boxes_demo"
+    hdr = HERE.parent / "probability-of-collision-for-safe-planning_amd" / "csrc" / "scene_boxes.hpp"
+    if not exe.exists() or exe.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", str(src), "-o", str(exe)], check=True)
+    return exe
+
+
+def run(demo, geoms, tmp_path):
+    f = tmp_path / "geoms.txt"
+    with open(f, "w") as fh:
+        for name, R, t, ext in geoms:
+            fh.write(name.replace(" ", "_") + " " + " ".join("%.17g" % v for v in list(R) + list(t) + list(ext)) + "\n")
+    out = subprocess.run([str(demo), str(f)], check=True, capture_output=True, text=True).stdout.splitlines()
+    boxes = np.array([[float(v) for v in ln.split()[1:]] for ln in out if ln.startswith("box")]).reshape(-1, 5)
+    return boxes, [ln for ln in out if ln.startswith("skipped")]
+
+
+def test_synthetic_scene_matches_the_python_loader(demo, pocs, tmp_path):
+    envxml = import_module("probability-of-collision-for-safe-planning_amd.envxml")
+    scene = HERE / "data" / "rotated_room.env.xml"
+    boxes, skipped = run(demo, envxml.load_env_geoms(scene), tmp_path)
+    want = envxml.load_env_xml(scene)["boxes"]
+    assert boxes.shape == want.shape == (3, 5)                    # floor and lintel dropped by the z filter
+    assert np.allclose(boxes, want, rtol=0, atol=1e-15)
+    assert not skipped
+
+
+def test_out_of_plane_rotation_is_reported_not_flattened(demo, tmp_path):
+    c, s = math.cos(0.3), math.sin(0.3)
+    tilted = ("tilted/box", [1, 0, 0, 0, c, -s, 0, s, c], [0.0, 0.0, 0.5], [0.2, 0.2, 0.2])     # about x
+    flat = ("flat/box", [0, -1, 0, 1, 0, 0, 0, 0, 1], [1.0, 2.0, 0.5], [0.3, 0.1, 0.2])         # 90 deg about z
+    boxes, skipped = run(demo, [tilted, flat], tmp_path)
+    assert boxes.shape == (1, 5) and np.allclose(boxes[0], [1.0, 2.0, 0.3, 0.1, math.pi / 2])
+    assert len(skipped) == 1 and "tilted" in skipped[0]
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference tree not mounted")
+@pytest.mark.parametrize("name", ["pr2test2", "pr2custom"])
+def test_reference_scenes_give_the_committed_tables(demo, pocs, tmp_path, name):
+    envxml = import_module("probability-of-collision-for-safe-planning_amd.envxml")
+    boxes, skipped = run(demo, envxml.load_env_geoms(REF / (name + ".env.xml")), tmp_path)
+    want = pocs.load_env(HERE / "golden" / (name + "_env.txt"))["boxes"]
+    assert boxes.shape == want.shape
+    assert np.allclose(boxes, want, rtol=0, atol=1e-15)           # yaw through atan2(sin, cos): to the last ulp or two
