@@ -202,6 +202,12 @@ def main():
         made = [make(b_hi, 0x5EED0001 + i, torch.cuda.Stream() if n_eng > 1 else None) for i in range(n_eng)]
         ctx = made[0][0]
         engines = [e for _, e in made]
+        # POCS_ONEHOP=1: the library's own exchange (IPC-mapped slots, one hop over xGMI, sum + mixture
+        # advance in one small launch) instead of one RCCL all-reduce per waypoint from Python
+        onehop = path == "gmm" and os.environ.get("POCS_ONEHOP") == "1"
+        if onehop:
+            for e in engines:
+                e.connect_onehop(dist if world > 1 else None, rank, world)
 
         def run_steps(sizes):
             p = 0.0
@@ -214,7 +220,7 @@ def main():
                 for e, b in zip(engines, group):
                     if e.batch != b:
                         e.set_batch(b)
-                p = par.run_gmm_pipelined(engines[:len(group)], dist)[0]
+                p = (par.run_gmm_onehop(engines[:len(group)]) if onehop else par.run_gmm_pipelined(engines[:len(group)], dist))[0]
             return p
 
     def fence():
@@ -245,7 +251,7 @@ def main():
             if engines[0].batch != b_hi:
                 engines[0].set_batch(b_hi)
             if path == "gmm":
-                par.run_gmm_pipelined(engines[:1], dist)
+                (par.run_gmm_onehop(engines[:1]) if onehop else par.run_gmm_pipelined(engines[:1], dist))
             else:
                 par.run_mc_sharded(engines[0], N, dist)
         else:
@@ -318,6 +324,8 @@ def main():
                        "waypoints": W, "samples_per_gpu": n_local, "components": K, "probability": prob,
                        "runs_per_launch": batch, "calls": chunks,
                        "engines_in_flight": len(engines) if engines else 1,
+                       "exchange": ("one-hop IPC slots (pocs_gmm_exchange_local)" if (sharded and path == "gmm" and os.environ.get("POCS_ONEHOP") == "1")
+                                    else "RCCL all-reduce per waypoint" if (sharded and path == "gmm") else "none (one GPU)"),
                        "total_samples_per_run": N,
                        "value_is": "batched throughput: `runs_per_launch` independent runs (the reference driver's 200-run loop) "
                                    "advance in lockstep per call; single_call_evals_per_s = one run per call",

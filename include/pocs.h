@@ -116,6 +116,18 @@ void* pocs_gmm_moments_ptr(pocs_ctx* ctx, int waypoint);              /* device 
 int pocs_gmm_moments_len(const pocs_ctx* ctx);                       /* batch x 11 x K: one exchange covers every run of the batch */
 int pocs_gmm_bind_moments(pocs_ctx* ctx, void* device_ptr, long long len_doubles);  /* optional: keep the [W][batch][11K] moments in a caller-owned device buffer (e.g. a torch tensor handed to all_reduce); NULL unbinds */
 int pocs_gmm_end(pocs_ctx* ctx, double* probability);
+/* The exchange without a collective library, for the GPUs of ONE node (11 K doubles per
+ * run and waypoint are latency, not bandwidth): every rank owns a small device buffer that all ranks map
+ * (HIP IPC); pocs_gmm_exchange_local(w) -- one small launch, after pocs_gmm_sample_local(w) -- writes this
+ * rank's moments of waypoint w into its slot of EVERY rank's buffer (one hop over xGMI), waits for the
+ * world's slots in its own buffer, adds them in rank order (every rank the same bits) and builds the
+ * mixture of waypoint w+1, so the sequence per waypoint is sample_local(w), exchange_local(w) -- no
+ * advance_local, no all-reduce.  Setup, once: pocs_xchg_create on every rank (returns the 64-byte IPC
+ * handle of its buffer), the caller gathers the handles (any host channel), pocs_xchg_connect(handles of
+ * rank 0 .. world-1, 64 bytes each).  world <= 8, batch <= 256. */
+int pocs_xchg_create(pocs_ctx* ctx, int world, int rank, void* handle64_out);
+int pocs_xchg_connect(pocs_ctx* ctx, const void* handles_world_x_64, int world);
+int pocs_gmm_exchange_local(pocs_ctx* ctx, int waypoint);
 /* MC: the shard's count of particles that collided at least once (device-synchronous). */
 int pocs_mc_run_local(pocs_ctx* ctx, unsigned long long* collided);            /* run 0 of the batch */
 int pocs_mc_get_batch_counts(pocs_ctx* ctx, unsigned long long* out, int cap);   /* every run of the last MC batch */

@@ -57,6 +57,9 @@ SIGNATURES = {
     "pocs_gmm_end": (C.c_int, [_vp, _dp]),
     "pocs_mc_run_local": (C.c_int, [_vp, C.POINTER(C.c_ulonglong)]),
     "pocs_mc_get_batch_counts": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.c_int]),
+    "pocs_xchg_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_void_p]),
+    "pocs_xchg_connect": (C.c_int, [_vp, C.c_void_p, C.c_int]),
+    "pocs_gmm_exchange_local": (C.c_int, [_vp, C.c_int]),
     "pocs_get_path_length": (C.c_int, [_vp]),
     "pocs_get_waypoint_probabilities": (C.c_int, [_vp, _dp, C.c_int]),
     "pocs_get_moments": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
@@ -265,6 +268,21 @@ class Context:
 
     def gmm_sample_local(self, w):
         self._chk(self.lib.pocs_gmm_sample_local(self.h, w))
+
+    def xchg_create(self, world, rank):
+        """This rank's exchange buffer; returns its 64-byte IPC handle (bytes) for the peers."""
+        h = C.create_string_buffer(64)
+        self._chk(self.lib.pocs_xchg_create(self.h, world, rank, C.cast(h, C.c_void_p)))
+        return h.raw
+
+    def xchg_connect(self, handles):
+        """handles: the 64-byte handles of rank 0 .. world-1, in rank order."""
+        blob = b"".join(handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        self._chk(self.lib.pocs_xchg_connect(self.h, C.cast(buf, C.c_void_p), len(handles)))
+
+    def gmm_exchange_local(self, w):
+        self._chk(self.lib.pocs_gmm_exchange_local(self.h, w))
 
     def gmm_moments_ptr(self, w):
         return self.lib.pocs_gmm_moments_ptr(self.h, w)

@@ -86,6 +86,12 @@ struct pocs_ctx {
   // ---- device state ----
   DevBuf d_env, d_sensor, d_hdr, d_chain, d_state, d_param, d_moments, d_partial;
   DevBuf d_sx, d_sy, d_st, d_flags, d_px, d_py, d_pt, d_hits, d_total, d_ticket, d_tables;
+  // one-hop exchange (pocs_xchg_*): this rank's buffer, the peers' buffers as mapped here
+  void* xchg_own = nullptr;
+  void* xchg_peer[POCS_XCHG_MAX_WORLD] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int xchg_world = 0, xchg_rank = -1;
+  bool xchg_connected = false;
+  unsigned long long xchg_calls = 0;     // begin/end sequences so far: part of every row's epoch
   double* ext_moments = nullptr;         // caller-owned moments buffer (multi-GPU), or null
   long long ext_moments_len = 0;
   void* h_pin = nullptr;                 // pinned staging: hdr | chain | state0 | moments | total
@@ -910,6 +916,9 @@ void pocs_destroy(pocs_ctx* c) {
                      &c->d_px, &c->d_py, &c->d_pt, &c->d_hits, &c->d_total, &c->d_ticket, &c->d_tables};
     for (DevBuf* b : all) if (b->p) hipFree(b->p);
     if (c->h_pin) hipHostFree(c->h_pin);
+    for (int q = 0; q < POCS_XCHG_MAX_WORLD; ++q)
+      if (c->xchg_peer[q] && c->xchg_peer[q] != c->xchg_own) (void)hipIpcCloseMemHandle(c->xchg_peer[q]);
+    if (c->xchg_own) (void)hipFree(c->xchg_own);
     hipStreamDestroy(c->own_stream);
   }
   delete c;
@@ -1195,6 +1204,7 @@ int pocs_gmm_begin(pocs_ctx* c) {
   if (int r = gmm_upload_run(c)) return r;
   if (int r = prof_begin(c, (size_t)c->W)) return r;
   if (int r = enqueue_ticket_reset(c)) return r;
+  c->xchg_calls += 1;
   c->gmm_open = true;
   c->last_gmm_wp = -1;
   c->last_gmm_adv = -1;
@@ -1237,6 +1247,56 @@ void* pocs_gmm_moments_ptr(pocs_ctx* c, int w) {
 
 int pocs_gmm_moments_len(const pocs_ctx* c) { return (c && c->K > 0) ? c->batch * c->K * POCS_NMOM : 0; }
 
+int pocs_xchg_create(pocs_ctx* c, int world, int rank, void* handle64) {
+  if (!c || !handle64) return POCS_E_ARG;
+  if (world < 1 || world > POCS_XCHG_MAX_WORLD || rank < 0 || rank >= world)
+    return fail(c, POCS_E_ARG, "exchange: world %d / rank %d outside 1..%d", world, rank, POCS_XCHG_MAX_WORLD);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "pocs.h promises a 64-byte handle");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->xchg_own) {
+    HIPCHK(c, hipMalloc(&c->xchg_own, POCS_XCHG_BYTES));
+    HIPCHK(c, hipMemset(c->xchg_own, 0, POCS_XCHG_BYTES));       // epoch 0 = nothing has landed
+  }
+  c->xchg_world = world; c->xchg_rank = rank; c->xchg_connected = false;
+  hipIpcMemHandle_t h;
+  HIPCHK(c, hipIpcGetMemHandle(&h, c->xchg_own));
+  memcpy(handle64, &h, sizeof h);
+  return POCS_OK;
+}
+
+int pocs_xchg_connect(pocs_ctx* c, const void* handles, int world) {
+  if (!c || !handles) return POCS_E_ARG;
+  if (!c->xchg_own || world != c->xchg_world) return fail(c, POCS_E_ORDER, "pocs_xchg_connect before pocs_xchg_create (or another world size)");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int q = 0; q < world; ++q) {
+    if (q == c->xchg_rank) { c->xchg_peer[q] = c->xchg_own; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)handles + 64 * (size_t)q, sizeof h);
+    if (c->xchg_peer[q] && c->xchg_peer[q] != c->xchg_own) { (void)hipIpcCloseMemHandle(c->xchg_peer[q]); c->xchg_peer[q] = nullptr; }
+    HIPCHK(c, hipIpcOpenMemHandle(&c->xchg_peer[q], h, hipIpcMemLazyEnablePeerAccess));
+  }
+  c->xchg_connected = true;
+  return POCS_OK;
+}
+
+int pocs_gmm_exchange_local(pocs_ctx* c, int w) {
+  if (!c) return POCS_E_ARG;
+  if (!c->gmm_open) return fail(c, POCS_E_ORDER, "pocs_gmm_exchange_local before pocs_gmm_begin");
+  if (!c->xchg_connected) return fail(c, POCS_E_ORDER, "pocs_gmm_exchange_local before pocs_xchg_connect");
+  if (w != c->last_gmm_wp || w != c->last_gmm_adv) return fail(c, POCS_E_ORDER, "exchange of waypoint %d out of sequence", w);
+  if (c->batch > POCS_XCHG_MAX_RUNS) return fail(c, POCS_E_ARG, "exchange: at most %d runs per call", POCS_XCHG_MAX_RUNS);
+  pocs_gmm_launch a;
+  fill_gmm_launch(c, &a, 0, 0, w);
+  pocs_xchg_dev x;
+  memset(&x, 0, sizeof x);
+  for (int q = 0; q < c->xchg_world; ++q) x.buf[q] = (double*)c->xchg_peer[q];
+  x.world = c->xchg_world; x.rank = c->xchg_rank;
+  x.epoch = (c->xchg_calls << 20) | (unsigned long long)(w + 1);
+  HIPCHK(c, pocs_launch_gmm_exchange(c->K, a, x, c->stream));
+  if (w + 1 < c->W) c->last_gmm_adv = w + 1;          // the exchange launch has built the mixture of w + 1
+  return POCS_OK;
+}
+
 int pocs_gmm_end(pocs_ctx* c, double* probability) {
   if (!c) return POCS_E_ARG;
   if (!c->gmm_open) return fail(c, POCS_E_ORDER, "pocs_gmm_end before pocs_gmm_begin");
@@ -1245,8 +1305,15 @@ int pocs_gmm_end(pocs_ctx* c, double* probability) {
   const PinLayout pl = pin_layout(c);
   HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.moments, moments_dev(c),
                            (size_t)c->W * c->batch * c->K * POCS_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.total + c->batch + 1, (unsigned*)c->d_ticket.p + POCS_SYNC_ABORT,
+                           sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   prefetch_next_batch(c);          // host chains of the next batch, while the queued work drains
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  {
+    unsigned gave_up = 0;
+    memcpy(&gave_up, (double*)c->h_pin + pl.total + c->batch + 1, sizeof gave_up);
+    if (gave_up) { c->gmm_open = false; return fail(c, POCS_E_DEVICE, "a bounded wait expired on the device (code %u: 4 = a peer's moments never arrived); results discarded", gave_up); }
+  }
   if (int r = prof_collect(c, (size_t)c->W)) return r;
   gmm_combine(c, (double*)c->h_pin + pl.moments, probability);
   c->gmm_open = false;

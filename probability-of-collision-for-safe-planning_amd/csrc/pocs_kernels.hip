@@ -243,13 +243,28 @@ __device__ __forceinline__ void advance_stage(const pocs_gmm_launch& a, int K, i
   constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
   const int ss = p.ss, NC = p.NC;
   const bool load_mom = w > 0 && !mom_in_lds;
-  const int n = ss + POCS_CHAIN_STRIDE + SEN;
-  stage_batched<4>(scratch, n + NC, tid, nthreads, [&](int i) -> double {
-    if (i < ss) return load_wt(&p.g_prev[i]);
-    if (i < ss + NC) return load_mom ? p.g_mom[i - ss] : p.l_mom[i - ss];     // in LDS already: rewritten with itself
-    if (i < ss + NC + POCS_CHAIN_STRIDE) return p.g_ch[i - ss - NC];
-    return p.g_sen[i - ss - NC - POCS_CHAIN_STRIDE];
-  });
+  // index space: [0, ss) state | [ss, ss + CH + SEN) chain record, sensor | then (only if wanted) the moments;
+  // l_mom is NOT touched when the caller has put the moments there
+  const int n = ss + POCS_CHAIN_STRIDE + SEN + (load_mom ? NC : 0);
+  for (int i0 = tid; i0 < n; i0 += nthreads * 4) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nthreads;
+      v[u] = 0.0;
+      if (i < ss) v[u] = load_wt(&p.g_prev[i]);
+      else if (i < ss + POCS_CHAIN_STRIDE) v[u] = p.g_ch[i - ss];
+      else if (i < ss + POCS_CHAIN_STRIDE + SEN) v[u] = p.g_sen[i - ss - POCS_CHAIN_STRIDE];
+      else if (i < n) v[u] = p.g_mom[i - ss - POCS_CHAIN_STRIDE - SEN];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nthreads;
+      if (i < ss) p.l_prev[i] = v[u];
+      else if (i < ss + POCS_CHAIN_STRIDE + SEN) p.l_ch[i - ss] = v[u];              // l_ch | l_sen are contiguous
+      else if (i < n) p.l_mom[i - ss - POCS_CHAIN_STRIDE - SEN] = v[u];
+    }
+  }
 }
 
 // one wave, after advance_stage (+ barrier): one component per lane
@@ -324,6 +339,77 @@ __global__ __launch_bounds__(128) void k_gmm_advance(pocs_gmm_launch a, int K) {
   __shared__ double s_adv[POCS_ADV_SCRATCH(POCS_MAX_GAUSSIANS)];
   __shared__ double s_spec[POCS_SPEC_SCRATCH(POCS_MAX_GAUSSIANS)];
   advance_block(a, K, a.waypoint, blockIdx.x, s_adv, s_spec, false, threadIdx.x, 128);      // one block per run
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sharded over the GPUs of a node: the moments of waypoint w of this rank's samples (moments[w][r],
+// left by k_gmm_step) -> the moments of the whole mixture, in ONE hop over xGMI instead of a ring
+// (11 K doubles per run are latency, not bandwidth), and straight on to the mixture
+// of waypoint w+1 -- exchange + advance in one small launch (one block per run) between two sampling
+// launches.  Every rank owns a buffer that all ranks have mapped; rank q writes its row into slot q
+// of EVERY buffer (system-scope stores: peers sit across xGMI), drains, meets, writes the slot's flag
+// = this waypoint's epoch; then waits for the world's flags in its OWN buffer and adds the slots in
+// rank order -- every rank the same sum, bit for bit, whatever the arrival order.  Slots alternate
+// with the waypoint's parity: a rank can only be one exchange ahead of another.  The wait is bounded
+// (30 s, once per call: later exchanges of a call that has given up return at once): on expiry the
+// call's give-up word is set and the host reports POCS_E_DEVICE.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double* xchg_row(double* buf, int parity, int src, int r) {
+  return buf + (((size_t)parity * POCS_XCHG_MAX_WORLD + src) * POCS_XCHG_MAX_RUNS + r) * POCS_XCHG_MAX_NC;
+}
+__device__ __forceinline__ unsigned long long* xchg_flag(double* buf, int parity, int src, int r) {
+  return reinterpret_cast<unsigned long long*>(buf + POCS_XCHG_DATA_DOUBLES) +
+         ((size_t)parity * POCS_XCHG_MAX_WORLD + src) * POCS_XCHG_MAX_RUNS + r;
+}
+__global__ __launch_bounds__(128) void k_gmm_exchange(pocs_gmm_launch a, pocs_xchg_dev x, int K) {
+  __shared__ double s_adv[POCS_ADV_SCRATCH(POCS_MAX_GAUSSIANS)];
+  __shared__ double s_spec[POCS_SPEC_SCRATCH(POCS_MAX_GAUSSIANS)];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, r = blockIdx.x, w = a.waypoint, NC = K * POCS_NMOM, parity = w & 1;
+  // an earlier exchange of this call gave up: do not wait another 5 s per waypoint, the call is lost
+  if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+  // my row -> slot `rank` of every rank's buffer
+  const double* mine = a.moments + ((size_t)w * a.nruns + r) * NC;
+  for (int i = tid; i < NC * x.world; i += 128) {
+    const int q = i / NC, c = i - q * NC;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(xchg_row(x.buf[q], parity, x.rank, r) + c),
+                       (unsigned long long)__double_as_longlong(mine[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: the rows are out before the flags
+  drain_stores();
+  __syncthreads();
+  if (tid < x.world)
+    __hip_atomic_store(xchg_flag(x.buf[tid], parity, x.rank, r), x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // every rank's row of this waypoint has landed in MY buffer?
+  if (tid == 0) s_ok = 1;
+  __syncthreads();
+  if (tid < x.world) {
+    const unsigned long long* f = xchg_flag(x.buf[x.rank], parity, tid, r);
+    const unsigned long long t0 = wall_clock64();
+    unsigned polls = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != x.epoch) {
+      __builtin_amdgcn_s_sleep(8);
+      if ((++polls & 255u) == 0u && wall_clock64() - t0 > 3000000000ull) {      // 30 s: ranks of a cold node start seconds apart
+        __hip_atomic_store(&a.sync[POCS_SYNC_ABORT], 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = 0;
+        break;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");            // system scope
+  __syncthreads();
+  if (!s_ok) return;
+  // the slots of my buffer, added in rank order
+  double* const l_mom = advance_ptrs(a, K, w + 1, r, s_adv).l_mom;
+  for (int c = tid; c < NC; c += 128) {
+    double tot = 0.0;
+    for (int q = 0; q < x.world; ++q)
+      tot += __longlong_as_double((long long)__hip_atomic_load(
+          reinterpret_cast<const unsigned long long*>(xchg_row(x.buf[x.rank], parity, q, r) + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    a.moments[((size_t)w * a.nruns + r) * NC + c] = tot;    // the mixture's moments replace this shard's
+    l_mom[c] = tot;
+  }
+  if (w + 1 < a.W) advance_block(a, K, w + 1, r, s_adv, s_spec, true, tid, 128);     // starts with a barrier after staging
 }
 
 // A wave leaves component `k`: its 16-lane row sums of (nFree, 9 sums) are ADDED to the task's LDS
@@ -1161,6 +1247,10 @@ hipError_t pocs_launch_copy(const void* src, void* dst, long long bytes, hipStre
   return hipGetLastError();
 }
 
+hipError_t pocs_launch_gmm_exchange(int K, const pocs_gmm_launch& a, const pocs_xchg_dev& x, hipStream_t s) {
+  hipLaunchKernelGGL(k_gmm_exchange, dim3(a.nruns), dim3(128), 0, s, a, x, K);
+  return hipGetLastError();
+}
 hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t s) {
   hipLaunchKernelGGL(k_gmm_advance, dim3(a.nruns), dim3(128), 0, s, a, K);
   return hipGetLastError();

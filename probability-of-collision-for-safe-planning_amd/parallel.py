@@ -45,6 +45,33 @@ def run_gmm_sharded(engine, dist=None):
     return engine.end()
 
 
+def run_gmm_onehop(engines):
+    """The same waypoint loop with the exchange done by the library itself (pocs_gmm_exchange_local:
+    every rank writes its moments into its slot of every rank's IPC-mapped buffer -- one hop over
+    xGMI --, adds the slots of its own buffer in rank order and builds the next mixture, all in one
+    small launch): per waypoint sample(w), exchange(w); no collective, no host in the loop.
+    Engines must have been connected (GpuEngine.connect_onehop).  Two engines alternate as in
+    run_gmm_pipelined."""
+    for e in engines:
+        with e.stream_ctx():
+            e.begin()
+            e.advance(0)
+    prev = None
+    for w in range(engines[0].W):
+        for e in engines:
+            with e.stream_ctx():
+                if prev is not None and len(engines) > 1:
+                    e.wait_event(prev)
+                e.sample(w)
+                prev = e.record_event()
+                e.exchange(w)
+    out = []
+    for e in engines:
+        with e.stream_ctx():
+            out.append(e.end())
+    return out
+
+
 def run_gmm_pipelined(engines, dist):
     """Two (or more) engines, each with its own batch of runs and its own stream, advanced waypoint
     by waypoint in turn: while one engine's moments are in the all-reduce (and its small mixture
@@ -134,6 +161,20 @@ class GpuEngine:
 
     def wait_event(self, ev):
         self.torch.cuda.current_stream().wait_event(ev)
+
+    def connect_onehop(self, dist, rank, world):
+        """Set up the library's own exchange: every rank creates its buffer, the 64-byte IPC handles go
+        round once over the host channel of the process group, every rank maps every buffer."""
+        mine = self.ctx.xchg_create(world, rank)
+        if dist is not None and world > 1:
+            handles = [None] * world
+            dist.all_gather_object(handles, mine)
+        else:
+            handles = [mine]
+        self.ctx.xchg_connect(handles)
+
+    def exchange(self, w):
+        self.ctx.gmm_exchange_local(w)
 
     def moments(self, w):
         n = self.batch * self.K * 11           # one exchange per waypoint covers every run of the batch

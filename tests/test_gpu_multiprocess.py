@@ -46,6 +46,61 @@ def _worker(rank, world, port, n_local, K, seed, batch, out):
     dist.destroy_process_group()
 
 
+def _worker_onehop(rank, world, port, n_local, K, seed, batch, out):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from importlib import import_module
+    import pocs_amd
+    par = import_module("probability-of-collision-for-safe-planning_amd.parallel")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan, env = pocs_amd.load_plan(), pocs_amd.load_env()
+    N = n_local * world
+    res = {}
+    for mode in ("gloo", "onehop", "onehop_again"):
+        c = pocs_amd.Context(0)
+        c.configure(plan, env, K=K, N=N, seed=seed)
+        e = par.GpuEngine(c, 56, K, N, rank=rank, world=world, per_rank=n_local, batch=batch, stream=torch.cuda.Stream())
+        if mode == "gloo":
+            par.run_gmm_pipelined([e], dist)
+        else:
+            e.connect_onehop(dist, rank, world)
+            par.run_gmm_onehop([e])
+            if mode == "onehop_again":                    # a second call on the same buffers: epochs move on
+                par.run_gmm_onehop([e])
+        torch.cuda.synchronize()
+        res[mode] = (list(e.probabilities()), np.array([c.moments(w, K) for w in range(56)]))
+        dist.barrier()
+        c.close()
+    if rank == 0:
+        np.savez(out, p_gloo=res["gloo"][0], p_one=res["onehop"][0], m_gloo=res["gloo"][1], m_one=res["onehop"][1],
+                 p_again=res["onehop_again"][0])
+    dist.destroy_process_group()
+
+
+def test_onehop_exchange_equals_the_collective(tmp_path, pocs, plan, env):
+    """pocs_gmm_exchange_local (IPC-mapped slots, rank-order sum, advance in the same launch) on two
+    processes sharing ONE card: bitwise what the gloo all-reduce path gives (two ranks: a + b either
+    way), run 0's moments of every waypoint included; and a second call on the same buffers redraws."""
+    import torch.multiprocessing as mp
+    n_local, K, seed, batch = 6000, 3, 91, 3
+    out = tmp_path / "res.npz"
+    port = 29900 + (os.getpid() % 90)
+    mp.spawn(_worker_onehop, args=(2, port, n_local, K, seed, batch, str(out)), nprocs=2, join=True)
+    got = np.load(out)
+    assert list(got["p_one"]) == list(got["p_gloo"])
+    assert np.array_equal(got["m_one"], got["m_gloo"])
+    assert list(got["p_again"]) != list(got["p_one"]) and all(0 < p < 1 for p in got["p_again"])
+    with pocs.Context(0) as c:                              # and both equal one process on the whole mixture
+        c.configure(plan, env, K=K, N=2 * n_local, seed=seed)
+        c.set_batch(batch)
+        c.run_gmm_estimation()
+        assert np.allclose(got["p_one"], c.batch_probabilities(), rtol=0, atol=1e-12)
+
+
 def test_two_processes_one_gpu_equal_one_process(tmp_path, pocs, plan, env):
     import torch.multiprocessing as mp
     n_local, K, seed, batch = 5000, 3, 77, 2
