@@ -7,15 +7,16 @@
 #include "pocs_model.h"
 
 #define POCS_BLOCK 256        // MC kernels
-// GMM kernels: TWO blocks per CU.  The sampling body keeps one component's sums per thread whatever
-// K is; 2 x 512 threads = four waves per SIMD at <= 128 VGPRs up to K = 5, 2 x 384 = three waves
-// beyond (the K = 8 instantiation wants more registers).  Two co-resident blocks instead of one fat
-// one: while one block is in the head or tail of a task (parameter staging, block reduction, the
-// drain of its stores, ticket, mixture advance) the other block's waves have the CU's issue slots.
+// GMM kernels: TWO blocks of 512 threads per CU = four waves per SIMD at <= 128 VGPRs.  The sampling body
+// keeps one component's sums per thread whatever K is, so one shape serves every K (measured at K = 8,
+// 10^7 samples, 16 runs: 2 x 512 0.39 of the HBM peak, 1 x 768 and 3 x 256 0.40, 2 x 384 0.31).  Two
+// co-resident blocks instead of one fat one: while one block is in the head or tail of a task (parameter
+// staging, block reduction, the drain of its stores, ticket, mixture advance) the other block's waves
+// have the CU's issue slots.
 #ifdef POCS_GMM_BLOCK                      // sweeps: force one size for every K
 #define POCS_GMM_BLOCK_OF(K) (POCS_GMM_BLOCK)
 #else
-#define POCS_GMM_BLOCK_OF(K) ((K) <= 5 ? 512 : 384)
+#define POCS_GMM_BLOCK_OF(K) 512
 #endif
 #ifdef POCS_GMM_BPC                        // sweeps
 #define POCS_GMM_BLOCKS_PER_CU POCS_GMM_BPC

@@ -54,7 +54,7 @@ def mem_ops(ops, prefix):
 
 
 @pytest.mark.parametrize("sub,streaming_bits", [("k_gmm_runILi3ELb1ELi512", "sc1"), ("k_gmm_stepILi3ELb1ELi512", "nt"),
-                                                ("k_gmm_runILi8ELb1ELi384", "sc1")])
+                                                ("k_gmm_runILi8ELb1ELi512", "sc1")])
 def test_gmm_kernel_handoff_shapes(listing, sub, streaming_bits):
     ops = kernel(listing, sub)
     stores = mem_ops(ops, "global_store")
