@@ -72,7 +72,7 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
          (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
 }
 
-// Stage the log / sector tables (3 KB) into LDS.
+// Stage the log / sector tables (12 KB) into LDS.
 __device__ __forceinline__ void stage_tables(const pocs_tables* __restrict__ g, pocs_tables* s_tab) {
   const double* src = reinterpret_cast<const double*>(g);
   double* dst = reinterpret_cast<double*>(s_tab);

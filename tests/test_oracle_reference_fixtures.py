@@ -93,10 +93,13 @@ def test_chol_is_lower_and_reads_lower_triangle(orc):
     assert orc.chol3_lower(np.diag([1.0, -1.0, 1.0]))[0] == 0
 
 
-def test_published_numbers_are_a_sanity_band_only(orc, plan, env):
-    """Table I (ajaay_paper.tex:874-877): MC 0.93 > GMM 0.64, both in (0.4, 1).  Our collision
-    model is not OpenRAVE's, so only the coarse ordering/band is asserted ("parity unpinned")."""
+def test_ordering_of_the_two_methods(orc, plan, env):
+    """Table I (ajaay_paper.tex:874-877) has MC well above GMM.  The published LEVELS (0.93 / 0.64)
+    belong to OpenRAVE's ODE check of the full PR2 mesh against walls and tables -- none of it in the
+    reference tree -- so no band is asserted here ("parity unpinned", DESIGN.md section 8, where this
+    build's 0.706 / 0.285 are reported next to the paper's numbers); the ordering is a property of the
+    two estimators and holds for any collision model that makes the corridor tight."""
     cfg = orc.config(plan, env, K=3)
     mc = [orc.run_mc(cfg, 100 + s, 2000)[0] / 2000.0 for s in range(6)]
     gm = [orc.run_gmm(cfg, 100 + s, 2000)["prob"] for s in range(6)]
-    assert 0.05 < np.mean(gm) <= 1.0 and 0.05 < np.mean(mc) <= 1.0
+    assert np.mean(mc) > np.mean(gm) > 0.0 and np.mean(mc) <= 1.0

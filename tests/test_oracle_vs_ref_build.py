@@ -1,7 +1,8 @@
 """The oracle restatement against the reference's OWN code: oracle/_ref/libpocs_ref.so is the
 reference's vendored Armadillo headers and GM_Model.h compiled where they lie (oracle/Makefile
 target `ref`, harness oracle/ref_harness.cpp).  CPU only.  Skips when the prebuilt library is
-absent (it is built wherever /root/reference is mounted and travels to the GPU box as a binary)."""
+absent (it is built wherever /root/reference is mounted -- the build container only: nothing derived from
+the reference travels to the GPU box)."""
 import ctypes as C
 from pathlib import Path
 
@@ -89,9 +90,10 @@ def test_final_combine_matches_armadillo(ref):
 
 
 def test_component_split_has_the_same_law_as_gm_model(ref, orc, plan, env, capfd):
-    """GM_Model draws N component indices from std::discrete_distribution (GM_Model.h:89-93); the
-    build draws one index per sample from its own stream.  Same multinomial law: compare the
-    counts of both with the expectation in units of the binomial standard deviation."""
+    """GM_Model draws N component indices from std::discrete_distribution (GM_Model.h:89-93) and counts
+    them; the build draws the counts directly (Multinomial(N, w) as conditional binomials, numerics
+    v6).  Same law: compare the counts of both with the expectation in units of the binomial standard
+    deviation."""
     cfg = orc.config(plan, env, K=3)
     state = orc.gmm_advance(cfg, orc.gmm_initial_state(cfg), None)
     w = np.array([0.2, 0.5, 0.3])
