@@ -283,11 +283,13 @@ def main():
             traffic_src = "%.3f B/eval measured at %d evals per launch (%s) x %d evals" % (
                 rec["bytes_per_launch"] / rec["evals_per_launch"], rec["evals_per_launch"], rec["source"].split(":")[0], units)
     copy_gbps = ctx.copy_bandwidth(1 << 30)       # measured streaming-copy ceiling of this GPU, same process
+    fill_gbps = ctx.fill_bandwidth(1 << 30)       # ... and the write-only one (the GMM kernels read nothing)
     roofline = {"bound": "hbm", "limiter": "FP64 VALU issue, not bandwidth: the SIMDs issue ~100 % of the time at ~210 vector instructions "
                                            "per evaluation (profiles/r02_*_pmc.txt); the HBM fraction below is what that arithmetic reaches",
                 "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "copy_GBps": copy_gbps, "frac_of_copy": achieved / copy_gbps if copy_gbps > 0 else None,
+                "fill_GBps": fill_gbps, "frac_of_fill": achieved / fill_gbps if fill_gbps > 0 else None,
                 "algorithmic_bytes_per_launch": bpe * units, "bytes_per_eval": bpe, "evals_per_launch": units,
                 "avg_kernel_us": avg_ms * 1e3,
                 "evals_per_s_in_kernel": units / (avg_ms * 1e-3) if avg_ms > 0 else 0.0}

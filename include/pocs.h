@@ -141,6 +141,7 @@ int pocs_get_host_chain(pocs_ctx* ctx, double* applied3, double* noisy3, double*
 long long pocs_copy_gmm_samples(pocs_ctx* ctx, double* xyt_aos, int16_t* flags, long long cap);  /* last waypoint's shard, 3 x n column-major like arma (x,y,theta triples) */
 long long pocs_copy_particles(pocs_ctx* ctx, double* xyt_aos, uint32_t* hits, long long cap);   /* mcparticles / particlecollisions, MCSimulator.h:105,108 */
 int pocs_measure_copy_bandwidth(pocs_ctx* ctx, long long bytes, double* gbps);  /* read+write GB/s of a plain streaming copy on this GPU: the measured HBM ceiling */
+int pocs_measure_fill_bandwidth(pocs_ctx* ctx, long long bytes, double* gbps);  /* written GB/s of a plain streaming fill: the write-only ceiling (the GMM kernels read nothing) */
 int pocs_get_kernel_time(pocs_ctx* ctx, double* total_ms, long long* launches);  /* hot-kernel time of the last run with POCS_OPT_PROFILE=1 */
 
 #ifdef __cplusplus

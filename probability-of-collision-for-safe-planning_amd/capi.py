@@ -68,6 +68,7 @@ SIGNATURES = {
     "pocs_copy_gmm_samples": (C.c_longlong, [_vp, _dp, C.POINTER(C.c_int16), C.c_longlong]),
     "pocs_copy_particles": (C.c_longlong, [_vp, _dp, C.POINTER(C.c_uint32), C.c_longlong]),
     "pocs_measure_copy_bandwidth": (C.c_int, [_vp, C.c_longlong, _dp]),
+    "pocs_measure_fill_bandwidth": (C.c_int, [_vp, C.c_longlong, _dp]),
     "pocs_get_kernel_time": (C.c_int, [_vp, _dp, C.POINTER(C.c_longlong)]),
 }
 
@@ -76,6 +77,31 @@ _lib = None
 
 def library_path():
     return _build.LIB
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel carries its own libamdhip64.so (soname
+    libamdhip64.so.7, the same as /opt/rocm's) and asks for it by FILE name: imported after libpocs.so
+    has pulled in /opt/rocm/lib/libamdhip64.so.7 it loads a second runtime, whose hipInit then finds
+    "no ROCm-capable device".  The other order is fine (libpocs.so asks by soname and binds to the copy
+    already loaded), so where such a wheel is installed its runtime is mapped first -- without importing
+    torch.  No torch: nothing happens, the system runtime serves libpocs.so."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for loc in (spec.submodule_search_locations or []) if spec else []:
+        rt = Path(loc) / "lib" / "libamdhip64.so"
+        if rt.exists():
+            try:
+                C.CDLL(str(rt), mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
 
 
 def load_library(build=True):
@@ -91,6 +117,7 @@ def load_library(build=True):
         path = str(_build.LIB)
     if not Path(path).exists():
         raise RuntimeError("libpocs.so is missing and was not built; the HIP path is the only path")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
@@ -351,6 +378,12 @@ class Context:
         """GB/s (read + written) of a plain streaming copy of nbytes on this GPU."""
         g = C.c_double()
         self._chk(self.lib.pocs_measure_copy_bandwidth(self.h, nbytes, C.byref(g)))
+        return g.value
+
+    def fill_bandwidth(self, nbytes=1 << 30):
+        """GB/s written by a plain streaming fill of nbytes on this GPU."""
+        g = C.c_double()
+        self._chk(self.lib.pocs_measure_fill_bandwidth(self.h, nbytes, C.byref(g)))
         return g.value
 
     def kernel_time(self):

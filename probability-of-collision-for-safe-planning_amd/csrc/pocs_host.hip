@@ -1443,6 +1443,33 @@ int pocs_measure_copy_bandwidth(pocs_ctx* c, long long bytes, double* gbps) {
   return rc;
 }
 
+// Measured write-only streaming bandwidth (GB/s written): a plain fill of `bytes`, best of 5.
+int pocs_measure_fill_bandwidth(pocs_ctx* c, long long bytes, double* gbps) {
+  if (!c || !gbps) return POCS_E_ARG;
+  if (bytes < 1024) return fail(c, POCS_E_ARG, "fill size too small");
+  HIPCHK(c, hipSetDevice(c->device));
+  bytes &= ~15LL;
+  void* a = nullptr;
+  HIPCHK(c, hipMalloc(&a, (size_t)bytes));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  double best = 0.0;
+  int rc = POCS_OK;
+  for (int i = 0; i < 6 && rc == POCS_OK; ++i) {
+    (void)hipEventRecord(e0, c->stream);
+    if (pocs_launch_fill(a, bytes, c->stream) != hipSuccess) rc = fail(c, POCS_E_DEVICE, "fill launch failed");
+    (void)hipEventRecord(e1, c->stream);
+    if (hipEventSynchronize(e1) != hipSuccess) rc = fail(c, POCS_E_DEVICE, "fill failed");
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (i > 0 && ms > 0.f) { const double g = (double)bytes / (ms * 1e-3) / 1e9; if (g > best) best = g; }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  *gbps = best;
+  return rc;
+}
+
 int pocs_get_kernel_time(pocs_ctx* c, double* total_ms, long long* launches) {
   if (!c) return POCS_E_ARG;
   if (total_ms) *total_ms = c->prof_ms;

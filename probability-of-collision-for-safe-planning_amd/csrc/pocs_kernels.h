@@ -122,6 +122,7 @@ hipError_t pocs_launch_gmm_run(int K, int nblk, const pocs_gmm_launch& a, hipStr
 hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t s);
 hipError_t pocs_launch_gmm_exchange(int K, const pocs_gmm_launch& a, const pocs_xchg_dev& x, hipStream_t s);   // grid = a.nruns
 hipError_t pocs_launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);
+hipError_t pocs_launch_fill(void* dst, long long bytes, hipStream_t s);
 hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s);
 hipError_t pocs_launch_mc_step(int nblk, const pocs_mc_launch& a, hipStream_t s);
 hipError_t pocs_launch_mc_fused(int nblk, const pocs_mc_launch& a, hipStream_t s);

@@ -573,15 +573,18 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
       for (int j = 0; j < K - 1; ++j) k += (cumn[j] <= gidx) ? 1 : 0;
       const double* p = &s_par[k * POCS_PARAM_STRIDE];
       // mvnrnd (glue_mvnrnd_meat.hpp:134-145): chol_lower * z + mean
-      const double x = fma(p[3], zz[h][0], p[0]);
-      const double y = fma(p[5], zz[h][1], fma(p[4], zz[h][0], p[1]));
-      const double t = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
+      xs[h] = fma(p[3], zz[h][0], p[0]);
+      ys[h] = fma(p[5], zz[h][1], fma(p[4], zz[h][0], p[1]));
+      ts[h] = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
+      ks[h] = k;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
 #if defined(POCS_ABLATE_COLLIDE)
-      const bool hit = x > t;
+      hits[h] = xs[h] > ts[h];
 #else
-      const bool hit = pocs_pose_collides(x, y, t, &fp, s_keep, nkeep, s_tab);
+      hits[h] = pocs_pose_collides(xs[h], ys[h], ts[h], &fp, s_keep, nkeep, s_tab);
 #endif
-      xs[h] = x; ys[h] = y; ts[h] = t; hits[h] = hit; ks[h] = k;
     }
 #if defined(POCS_ABLATE_MOMENTS)
     acc[1] += xs[0] + ys[0] + ts[0] + xs[1]; acc[0] += (hits[0] || (two && ks[1] == 0)) ? 0.0 : 1.0;
@@ -594,8 +597,9 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
     // in the wave are visited in increasing order (scalar loop), the previous component's sums being
     // flushed to the LDS rows first.
     {
-      // sample indices grow with the lane: lane 0 holds the wave's first component, lane 63 its last
-      const int klo = __builtin_amdgcn_readfirstlane(live ? ks[0] : K);
+      // sample indices grow with the lane: the wave's first LIVE lane holds its first component, lane 63 its last
+      const unsigned long long live_mask = __ballot(live);
+      const int klo = live_mask ? __builtin_amdgcn_readlane(ks[0], (int)__builtin_ctzll(live_mask)) : K;
       const bool all_two = __ballot(two) == ~0ull;
       const int khi = all_two ? __builtin_amdgcn_readlane(ks[1], 63) : K - 1;
       auto add = [&](const double ind, const double x, const double y, const double t) {
@@ -624,10 +628,11 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
     }
 #endif
     if (STORE && live) {
-      // Both poses of the pair leave together.  For the last sample of an odd shard the second
-      // slot is the pair's unused twin: it lands in the padding element of the run's slice
-      // (sample_stride >= count + 1 then) and is never read back.  Written once, never re-read by
-      // the kernels.
+      // Both poses of the pair leave together.  For the last sample of an odd shard the second slot is
+      // the pair's unused twin: it lands in the padding element of the run's slice (sample_stride >=
+      // count + 1 then) and is never read back.  Written once, never re-read by the kernels.
+      // (Issuing the three pose stores BEFORE the footprint test, so that they drain under it, was
+      // measured equal: r02, 507 vs 496 us per 64-run launch.)
       const size_t ub = 2 * (size_t)base;
       const int fl = (hits[0] ? 1 : 0) | ((two && hits[1]) ? 0x10000 : 0);
       if (WT) {                                    // k_gmm_run: write-through, see store16_wt
@@ -1241,6 +1246,22 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_copy(const double2* __restrict__
 #pragma unroll
     for (int u = 0; u < 4; ++u) if (i + u * POCS_BLOCK < n) __builtin_nontemporal_store(v[u], d + i + u * POCS_BLOCK);
   }
+}
+// Plain streaming FILL: what a write-only stream reaches on this GPU -- the GMM kernels read nothing, so
+// this, not the copy rate, is the bandwidth ceiling they could run into (bench.py "fill_GBps").
+__global__ __launch_bounds__(POCS_BLOCK) void k_fill(double2* __restrict__ dst, long long n, double v) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  v2d* d = reinterpret_cast<v2d*>(dst);
+  const v2d x = {v, v};
+  const long long stride = (long long)gridDim.x * POCS_BLOCK * 4;
+  for (long long i = (long long)blockIdx.x * POCS_BLOCK * 4 + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i + u * POCS_BLOCK < n) __builtin_nontemporal_store(x, d + i + u * POCS_BLOCK);
+  }
+}
+hipError_t pocs_launch_fill(void* dst, long long bytes, hipStream_t s) {
+  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(POCS_BLOCK), 0, s, (double2*)dst, bytes / 16, 1.5);
+  return hipGetLastError();
 }
 hipError_t pocs_launch_copy(const void* src, void* dst, long long bytes, hipStream_t s) {
   hipLaunchKernelGGL(k_copy, dim3(8192), dim3(POCS_BLOCK), 0, s, (const double2*)src, (double2*)dst, bytes / 16);

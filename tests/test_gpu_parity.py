@@ -370,6 +370,31 @@ def test_shards_partition_the_work(ctx, orc, plan, env):
     assert n0 + n1 == ctx.mc_run_local() == orc.run_mc(cfg, 21, N)[0]
 
 
+@pytest.mark.parametrize("first,count", [(0, 20001), (2 * (1024 + 512 + 100), 7001), (2 * 1023, 2), (2 * 511, 4100),
+                                         (4096 + 2 * 37, 1), (10000, 10001)])
+def test_shards_anywhere(ctx, orc, plan, env, first, count):
+    """A shard may start at any even index and have any length: its samples, flags and moments of
+    waypoint 0 are the oracle's for exactly that index range (draws are keyed by the global index)."""
+    K, N = 3, 20001
+    cfg = orc.config(plan, env, K=K)
+    ctx.configure(plan, env, K=K, N=N, seed=19)
+    ctx.set_shard(first, count)
+    try:
+        ctx.gmm_begin()
+        ctx.gmm_step_local(0)
+        xyz, flags = ctx.gmm_samples(count)
+        for w in range(1, 56):
+            ctx.gmm_step_local(w)
+        ctx.gmm_end()
+        got = ctx.moments(0, K)
+    finally:
+        ctx.set_shard()
+    st0 = orc.gmm_advance(cfg, orc.gmm_initial_state(cfg), None)
+    mom, samples, oflags, _ = orc.gmm_waypoint(cfg, 19, 0, st0, first, count, want_samples=True, n_total=N)
+    assert np.array_equal(flags, oflags) and np.array_equal(xyz, samples)
+    close_moments(got, mom)
+
+
 @pytest.mark.parametrize("K,N", [(3, 2), (3, 3), (8, 9), (2, 1), (8, 40)])
 def test_degenerate_mixtures_match_oracle(ctx, orc, plan, env, K, N):
     """Tiny N: components run out of survivors (< 2) or all samples collide -- cases the reference
