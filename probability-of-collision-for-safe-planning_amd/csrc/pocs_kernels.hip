@@ -511,6 +511,15 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
   double cumn[K > 1 ? K - 1 : 1];                   // cumulative component counts (wave-uniform)
 #pragma unroll
   for (int j = 0; j < K - 1; ++j) cumn[j] = s_par[j * POCS_PARAM_STRIDE + 9];
+  // A wave's 128 samples of an iteration nearly always lie inside ONE component block and inside the
+  // shard: the component is then a scalar (looked up again when the wave crosses into the next block),
+  // its parameters are read at one LDS address and nobody compares indices per lane.  (Keeping the nine
+  // parameters in scalar registers instead spills scalar registers: measured 5 % slower at K = 3.)
+  //   seg_end = global index up to which (exclusive) whole waves belong to component kw and exist
+  const long long wave_first = 2 * (long long)(__builtin_amdgcn_readfirstlane(tid >> 6) * 64);
+  const long long g_end = a.first + a.count;
+  long long seg_end = 0;
+  int kw = 0;
   // The loop counter is wave-uniform (SGPRs) and the lane adds its tid: the store addresses are a
   // scalar base per iteration plus a constant 16*tid, no per-lane 64-bit address arithmetic.
   double* const xr = a.x + (size_t)r * a.sample_stride;          // this run's slice (sample_stride is even)
@@ -563,20 +572,42 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
     double xs[2], ys[2], ts[2];
     bool hits[2];
     int ks[2];
+    const long long g0 = a.first + 2 * base + wave_first;       // global index of the wave's first sample
+    bool whole = g0 + 128 <= seg_end;
+    if (!whole) {                                               // scalar: a block boundary, or the shard's end
+      int kk = 0;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      // component of the sample (GM_Model.h:87-107: counts[k] samples per component, one block
-      // after the other): the first component whose cumulative count exceeds the global index
-      const double gidx = gbase + (double)h;
-      int k = 0;
+      for (int j = 0; j < K - 1; ++j) kk += (cumn[j] <= (double)g0) ? 1 : 0;
+      kw = __builtin_amdgcn_readfirstlane(kk);
+      const long long blk_end = kw < K - 1 ? (long long)s_par[kw * POCS_PARAM_STRIDE + 9] : g_end;
+      seg_end = uniform64(blk_end < g_end ? blk_end : g_end);
+      whole = g0 + 128 <= seg_end;
+    }
+    if (whole) {
+      const double* p = &s_par[kw * POCS_PARAM_STRIDE];         // one address for the wave: broadcast reads
 #pragma unroll
-      for (int j = 0; j < K - 1; ++j) k += (cumn[j] <= gidx) ? 1 : 0;
-      const double* p = &s_par[k * POCS_PARAM_STRIDE];
-      // mvnrnd (glue_mvnrnd_meat.hpp:134-145): chol_lower * z + mean
-      xs[h] = fma(p[3], zz[h][0], p[0]);
-      ys[h] = fma(p[5], zz[h][1], fma(p[4], zz[h][0], p[1]));
-      ts[h] = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
-      ks[h] = k;
+      for (int h = 0; h < 2; ++h) {
+        // mvnrnd (glue_mvnrnd_meat.hpp:134-145): chol_lower * z + mean
+        xs[h] = fma(p[3], zz[h][0], p[0]);
+        ys[h] = fma(p[5], zz[h][1], fma(p[4], zz[h][0], p[1]));
+        ts[h] = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
+        ks[h] = kw;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // component of the sample (GM_Model.h:87-107: counts[k] samples per component, one block
+        // after the other): the first component whose cumulative count exceeds the global index
+        const double gidx = gbase + (double)h;
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) k += (cumn[j] <= gidx) ? 1 : 0;
+        const double* p = &s_par[k * POCS_PARAM_STRIDE];
+        xs[h] = fma(p[3], zz[h][0], p[0]);
+        ys[h] = fma(p[5], zz[h][1], fma(p[4], zz[h][0], p[1]));
+        ts[h] = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
+        ks[h] = k;
+      }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -597,11 +628,6 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
     // in the wave are visited in increasing order (scalar loop), the previous component's sums being
     // flushed to the LDS rows first.
     {
-      // sample indices grow with the lane: the wave's first LIVE lane holds its first component, lane 63 its last
-      const unsigned long long live_mask = __ballot(live);
-      const int klo = live_mask ? __builtin_amdgcn_readlane(ks[0], (int)__builtin_ctzll(live_mask)) : K;
-      const bool all_two = __ballot(two) == ~0ull;
-      const int khi = all_two ? __builtin_amdgcn_readlane(ks[1], 63) : K - 1;
       auto add = [&](const double ind, const double x, const double y, const double t) {
         const double xm = ind * x, ym = ind * y, tm = ind * t;
         acc[0] += ind;
@@ -609,11 +635,15 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
         acc[4] = fma(xm, x, acc[4]); acc[5] = fma(xm, y, acc[5]); acc[6] = fma(xm, t, acc[6]);
         acc[7] = fma(ym, y, acc[7]); acc[8] = fma(ym, t, acc[8]); acc[9] = fma(tm, t, acc[9]);
       };
-      if (all_two && klo == khi) {                                            // scalar condition: the usual case
-        if (klo != kcur) { flush_component<NC>(s_red, kcur, acc, tid); kcur = klo; }
+      if (whole) {                                                            // scalar condition: the usual case
+        if (kw != kcur) { flush_component<NC>(s_red, kcur, acc, tid); kcur = kw; }
 #pragma unroll
         for (int h = 0; h < 2; ++h) add(hits[h] ? 0.0 : 1.0, xs[h], ys[h], ts[h]);
       } else {
+        // sample indices grow with the lane: the wave's first LIVE lane holds its first component, lane 63 its last
+        const unsigned long long live_mask = __ballot(live);
+        const int klo = live_mask ? __builtin_amdgcn_readlane(ks[0], (int)__builtin_ctzll(live_mask)) : K;
+        const int khi = __ballot(two) == ~0ull ? __builtin_amdgcn_readlane(ks[1], 63) : K - 1;
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) {
           if (kk < klo || kk > khi) continue;                                 // scalar compares
