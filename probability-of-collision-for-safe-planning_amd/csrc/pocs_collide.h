@@ -72,6 +72,11 @@ POCS_HD bool pocs_pose_collides(double x, double y, double th, const pocs_footpr
   pocs_sincos_tab(th, T, &sn, &cs);
   double px = x, py = y;
   if (!(fp->dx == 0.0 && fp->dy == 0.0)) {      // a centred footprint skips x + (c*0 - s*0) == x
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keeps this a (scalar) BRANCH: left alone the compiler computes both and selects, 10 vector
+    // instructions per pose for a footprint that is centred in every scene of the reference
+    asm volatile("; offset footprint");
+#endif
     px = x + fma(cs, fp->dx, -(sn * fp->dy));
     py = y + fma(sn, fp->dx, cs * fp->dy);
   }

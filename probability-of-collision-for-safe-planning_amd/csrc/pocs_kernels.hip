@@ -38,6 +38,7 @@
 // per-block partial row; partials are combined in a fixed order so results are bitwise
 // reproducible run to run (no float atomics).
 #include "pocs_kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -511,11 +512,8 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
   double cumn[K > 1 ? K - 1 : 1];                   // cumulative component counts (wave-uniform)
 #pragma unroll
   for (int j = 0; j < K - 1; ++j) cumn[j] = s_par[j * POCS_PARAM_STRIDE + 9];
-  // A wave's 128 samples of an iteration nearly always lie inside ONE component block and inside the
-  // shard: the component is then a scalar (looked up again when the wave crosses into the next block),
-  // its parameters are read at one LDS address and nobody compares indices per lane.  (Keeping the nine
-  // parameters in scalar registers instead spills scalar registers: measured 5 % slower at K = 3.)
-  //   seg_end = global index up to which (exclusive) whole waves belong to component kw and exist
+  // (Keeping the wave's component parameters in scalar registers instead of reading them at one LDS
+  // address spills scalar registers: measured 5 % slower at K = 3.)
   const long long wave_first = 2 * (long long)(__builtin_amdgcn_readfirstlane(tid >> 6) * 64);
   const long long g_end = a.first + a.count;
   long long seg_end = 0;
@@ -537,7 +535,12 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
   int prio_it = prio_slot;
 #endif
   POCS_STAMP(2);
-  for (long long base = c_begin * TB; base < c_end * TB; base += TB) {
+  // ONE iteration = 2 * TB samples, one pair per thread.  WHOLE (compile time): the wave's 128 samples lie
+  // inside component block kw and inside the shard -- every lane live, both samples of its pair exist,
+  // the component is the scalar kw == kcur.  Otherwise: the general case (a block boundary inside the
+  // wave, the shard's last chunk), every decision per lane.  Same arithmetic per sample either way.
+  auto iteration = [&](auto whole_tag, const long long base) __attribute__((always_inline)) {
+    constexpr bool WHOLE = decltype(whole_tag)::value;
 #if !defined(POCS_NO_PRIO_ROTATION)
     switch (prio_it++ & 3) {                       // s_setprio takes an immediate
       case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -547,7 +550,7 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
     }
 #endif
     const long long lp = base + tid;
-    const bool live = lp < npairs;                 // a lane past the end computes, masked: the row sums below need every lane
+    const bool live = WHOLE || lp < npairs;        // a lane past the end computes, masked: the row sums below need every lane
     double zz[2][3];
     uint32_t spare[2];
 #if defined(POCS_ABLATE_RNG)          // timing-only builds (tools/ablate.sh): outputs are wrong
@@ -567,50 +570,27 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
     pocs_normal3_pair(seed_it, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, s_tab, zz[0], zz[1], &spare[0], &spare[1]);
 #endif
     const long long i0 = 2 * lp;
-    const bool two = live && (i0 + 1) < a.count;  // false only for the last sample of an odd shard
-    const double gbase = first_d + (double)i0;     // global index of sample 2*lp (exact: < 2^53)
+    const bool two = WHOLE || (live && (i0 + 1) < a.count);  // false only for the last sample of an odd shard
     double xs[2], ys[2], ts[2];
     bool hits[2];
     int ks[2];
-    const long long g0 = a.first + 2 * base + wave_first;       // global index of the wave's first sample
-    bool whole = g0 + 128 <= seg_end;
-    if (!whole) {                                               // scalar: a block boundary, or the shard's end
-      int kk = 0;
-#pragma unroll
-      for (int j = 0; j < K - 1; ++j) kk += (cumn[j] <= (double)g0) ? 1 : 0;
-      kw = __builtin_amdgcn_readfirstlane(kk);
-      const long long blk_end = kw < K - 1 ? (long long)s_par[kw * POCS_PARAM_STRIDE + 9] : g_end;
-      seg_end = uniform64(blk_end < g_end ? blk_end : g_end);
-      whole = g0 + 128 <= seg_end;
-    }
-    if (whole) {
-      const double* p = &s_par[kw * POCS_PARAM_STRIDE];         // one address for the wave: broadcast reads
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        // mvnrnd (glue_mvnrnd_meat.hpp:134-145): chol_lower * z + mean
-        xs[h] = fma(p[3], zz[h][0], p[0]);
-        ys[h] = fma(p[5], zz[h][1], fma(p[4], zz[h][0], p[1]));
-        ts[h] = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
-        ks[h] = kw;
-      }
-    } else {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        // component of the sample (GM_Model.h:87-107: counts[k] samples per component, one block
-        // after the other): the first component whose cumulative count exceeds the global index
-        const double gidx = gbase + (double)h;
-        int k = 0;
-#pragma unroll
-        for (int j = 0; j < K - 1; ++j) k += (cumn[j] <= gidx) ? 1 : 0;
-        const double* p = &s_par[k * POCS_PARAM_STRIDE];
-        xs[h] = fma(p[3], zz[h][0], p[0]);
-        ys[h] = fma(p[5], zz[h][1], fma(p[4], zz[h][0], p[1]));
-        ts[h] = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
-        ks[h] = k;
-      }
-    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+      int k = kw;                                   // WHOLE: one LDS address for the wave, broadcast reads
+      if (!WHOLE) {
+        // component of the sample (GM_Model.h:87-107: counts[k] samples per component, one block
+        // after the other): the first component whose cumulative count exceeds the global index
+        const double gidx = (first_d + (double)i0) + (double)h;   // exact: < 2^53
+        k = 0;
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) k += (cumn[j] <= gidx) ? 1 : 0;
+      }
+      const double* p = &s_par[k * POCS_PARAM_STRIDE];
+      // mvnrnd (glue_mvnrnd_meat.hpp:134-145): chol_lower * z + mean
+      xs[h] = fma(p[3], zz[h][0], p[0]);
+      ys[h] = fma(p[5], zz[h][1], fma(p[4], zz[h][0], p[1]));
+      ts[h] = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
+      ks[h] = k;
 #if defined(POCS_ABLATE_COLLIDE)
       hits[h] = xs[h] > ts[h];
 #else
@@ -620,39 +600,41 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
 #if defined(POCS_ABLATE_MOMENTS)
     acc[1] += xs[0] + ys[0] + ts[0] + xs[1]; acc[0] += (hits[0] || (two && ks[1] == 0)) ? 0.0 : 1.0;
 #else
-    // T1 sums over the collision-free samples of the component being accumulated: with ind = 1.0 for
-    // such a sample and 0.0 otherwise, (xm, ym, tm) = ind * (x, y, t) and
-    //   acc += (ind, xm, ym, tm, xm x, xm y, xm t, ym y, ym t, tm t)      (the products inside the fma).
-    // A wave sits in ONE component block except where two blocks meet (and every lane is live except
-    // in a shard's last chunk): then ind is just "did not collide".  Otherwise the components present
-    // in the wave are visited in increasing order (scalar loop), the previous component's sums being
-    // flushed to the LDS rows first.
-    {
-      auto add = [&](const double ind, const double x, const double y, const double t) {
-        const double xm = ind * x, ym = ind * y, tm = ind * t;
-        acc[0] += ind;
-        acc[1] += xm; acc[2] += ym; acc[3] += tm;
-        acc[4] = fma(xm, x, acc[4]); acc[5] = fma(xm, y, acc[5]); acc[6] = fma(xm, t, acc[6]);
-        acc[7] = fma(ym, y, acc[7]); acc[8] = fma(ym, t, acc[8]); acc[9] = fma(tm, t, acc[9]);
-      };
-      if (whole) {                                                            // scalar condition: the usual case
-        if (kw != kcur) { flush_component<NC>(s_red, kcur, acc, tid); kcur = kw; }
+    // T1 sums over the collision-free samples of the component being accumulated:
+    //   acc += (1, x, y, t, x x, x y, x t, y y, y t, t t)      (the products inside the fma).
+    if (WHOLE) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) add(hits[h] ? 0.0 : 1.0, xs[h], ys[h], ts[h]);
-      } else {
-        // sample indices grow with the lane: the wave's first LIVE lane holds its first component, lane 63 its last
-        const unsigned long long live_mask = __ballot(live);
-        const int klo = live_mask ? __builtin_amdgcn_readlane(ks[0], (int)__builtin_ctzll(live_mask)) : K;
-        const int khi = __ballot(two) == ~0ull ? __builtin_amdgcn_readlane(ks[1], 63) : K - 1;
+      for (int h = 0; h < 2; ++h) {
+        if (!hits[h]) {                             // the few lanes that collided sit this out
+          const double x = xs[h], y = ys[h], t = ts[h];
+          acc[0] += 1.0;
+          acc[1] += x; acc[2] += y; acc[3] += t;
+          acc[4] = fma(x, x, acc[4]); acc[5] = fma(x, y, acc[5]); acc[6] = fma(x, t, acc[6]);
+          acc[7] = fma(y, y, acc[7]); acc[8] = fma(y, t, acc[8]); acc[9] = fma(t, t, acc[9]);
+        }
+      }
+    } else {
+      // The components present in the wave are visited in increasing order (scalar loop), the previous
+      // component's sums being flushed to the LDS rows first; with ind = 1.0 for a surviving sample of the
+      // component and 0.0 otherwise, (xm, ym, tm) = ind * (x, y, t) enter the sums -- a sample that does not
+      // count adds +-0 to every one of them, which is why the WHOLE form above gives the same bits.
+      // Sample indices grow with the lane: the wave's first LIVE lane holds its first component, lane 63 its last.
+      const unsigned long long live_mask = __ballot(live);
+      const int klo = live_mask ? __builtin_amdgcn_readlane(ks[0], (int)__builtin_ctzll(live_mask)) : K;
+      const int khi = __ballot(two) == ~0ull ? __builtin_amdgcn_readlane(ks[1], 63) : K - 1;
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) {
-          if (kk < klo || kk > khi) continue;                                 // scalar compares
-          if (kk != kcur) { flush_component<NC>(s_red, kcur, acc, tid); kcur = kk; }
+      for (int kk = 0; kk < K; ++kk) {
+        if (kk < klo || kk > khi) continue;                                 // scalar compares
+        if (kk != kcur) { flush_component<NC>(s_red, kcur, acc, tid); kcur = kk; }
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const bool sel = (h == 0 ? live : two) && ks[h] == kk;
-            add((sel && !hits[h]) ? 1.0 : 0.0, xs[h], ys[h], ts[h]);
-          }
+        for (int h = 0; h < 2; ++h) {
+          const bool sel = (h == 0 ? live : two) && ks[h] == kk;
+          const double ind = (sel && !hits[h]) ? 1.0 : 0.0;
+          const double xm = ind * xs[h], ym = ind * ys[h], tm = ind * ts[h];
+          acc[0] += ind;
+          acc[1] += xm; acc[2] += ym; acc[3] += tm;
+          acc[4] = fma(xm, xs[h], acc[4]); acc[5] = fma(xm, ys[h], acc[5]); acc[6] = fma(xm, ts[h], acc[6]);
+          acc[7] = fma(ym, ys[h], acc[7]); acc[8] = fma(ym, ts[h], acc[8]); acc[9] = fma(tm, ts[h], acc[9]);
         }
       }
     }
@@ -676,6 +658,34 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
         __builtin_nontemporal_store((v2d){ts[0], ts[1]}, reinterpret_cast<v2d*>(tr + ub) + tid);
         __builtin_nontemporal_store(fl, reinterpret_cast<int*>(fr + ub) + tid);
       }
+    }
+  };
+  // A wave's 128 samples of an iteration nearly always lie inside ONE component block and inside the shard:
+  // those iterations run in the inner loop below, which knows nothing of the general case (no per-lane
+  // index compares, no masks, no flush; the accumulators stay where they are).  The wave's position is
+  // looked up again (scalar) whenever the next iteration is not of that kind.
+  //   seg_end = global index up to which (exclusive) whole waves belong to component kw and exist
+  const long long end = c_end * TB;
+  for (long long base = c_begin * TB; base < end;) {
+    long long g0 = a.first + 2 * base + wave_first;                         // global index of the wave's first sample
+    {
+      int kk = 0;
+#pragma unroll
+      for (int j = 0; j < K - 1; ++j) kk += (cumn[j] <= (double)g0) ? 1 : 0;
+      kw = __builtin_amdgcn_readfirstlane(kk);
+      const long long blk_end = kw < K - 1 ? (long long)s_par[kw * POCS_PARAM_STRIDE + 9] : g_end;
+      seg_end = uniform64(blk_end < g_end ? blk_end : g_end);
+    }
+    if (g0 + 128 <= seg_end) {
+      if (kw != kcur) { flush_component<NC>(s_red, kcur, acc, tid); kcur = kw; }
+      do {
+        iteration(std::true_type{}, base);
+        base += TB;
+        g0 += 2 * TB;
+      } while (base < end && g0 + 128 <= seg_end);
+    } else {
+      iteration(std::false_type{}, base);
+      base += TB;
     }
   }
 #if !defined(POCS_NO_PRIO_ROTATION)

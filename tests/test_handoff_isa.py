@@ -58,9 +58,10 @@ def mem_ops(ops, prefix):
 def test_gmm_kernel_handoff_shapes(listing, sub, streaming_bits):
     ops = kernel(listing, sub)
     stores = mem_ops(ops, "global_store")
-    # the sample stream: three 16-byte pose stores (+ one flags store) per pair of samples
+    # the sample stream: three 16-byte pose stores (+ one flags store) per pair of samples, in each of
+    # the two forms of the iteration (whole-wave and general)
     poses = [o for o in stores if o.startswith("global_store_dwordx4")]
-    assert len(poses) == 3 and all(streaming_bits in o.split() for o in poses), stores
+    assert len(poses) == 6 and all(streaming_bits in o.split() for o in poses), stores
     flags = [o for o in stores if o.startswith("global_store_dword ")]
     assert flags and all(("sc1" in o.split()) or ("nt" in o.split() and streaming_bits == "nt") for o in flags), flags
     # handed-off bytes (partial row, state, param): 8-byte write-through stores
