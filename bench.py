@@ -90,6 +90,70 @@ def cpu_baseline(plan, env, K, W, path, budget_evals):
     return out
 
 
+class BoardProbe:
+    """Shader clock and socket power of one GPU while the kernels run, read from the amdgpu hwmon files
+    (no subprocess): the GMM kernel runs at the board's power cap, and the clock the cap leaves it is
+    part of the roofline's story.  Everything here is best effort: a missing file gives None."""
+
+    def __init__(self, pci_bus_id=None):
+        import glob
+        self.dirs = []
+        for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+            if os.path.exists(h + "/power1_input") and os.path.exists(h + "/freq1_input"):
+                dev = os.path.realpath(h + "/../..")
+                self.dirs.append((h, dev))
+        if pci_bus_id:
+            hit = [d for d in self.dirs if os.path.basename(d[1]).lower().endswith(pci_bus_id.lower())]
+            self.dirs = hit or self.dirs
+        self.samples = {h: [] for h, _ in self.dirs}
+        self.thread, self.stop_flag = None, False
+
+    @staticmethod
+    def _num(path):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0])
+        except (OSError, ValueError, IndexError):
+            return None
+
+    def _loop(self):
+        while not self.stop_flag:
+            for h, _ in self.dirs:
+                pw, fq = self._num(h + "/power1_input"), self._num(h + "/freq1_input")
+                if pw is not None and fq is not None:
+                    self.samples[h].append((pw * 1e-6, fq * 1e-6))
+            time.sleep(0.02)
+
+    def start(self):
+        if self.dirs:
+            import threading
+            self.thread = threading.Thread(target=self._loop, daemon=True)
+            self.thread.start()
+
+    def stop(self):
+        if self.thread is None:
+            return None
+        self.stop_flag = True
+        self.thread.join()
+        # several cards visible and no bus id to tell them apart: the busy one is the one drawing power
+        best = max(self.samples.items(), key=lambda kv: sum(p for p, _ in kv[1]) / max(len(kv[1]), 1), default=None)
+        if not best or not best[1]:
+            return None
+        h, smp = best
+        dev = dict(self.dirs)[h]
+        peak = None
+        try:
+            with open(dev + "/pp_dpm_sclk") as f:
+                peak = max(float(t[:-3]) for t in f.read().replace("*", " ").split() if t.lower().endswith("mhz"))
+        except (OSError, ValueError):
+            pass
+        cap = self._num(h + "/power1_cap")
+        return {"sclk_MHz": sum(f for _, f in smp) / len(smp), "sclk_peak_MHz": peak,
+                "power_W": max(p for p, _ in smp), "power_cap_W": cap * 1e-6 if cap else None, "samples": len(smp),
+                "source": "amdgpu hwmon freq1_input (mean) / power1_input (max) polled for 0.4 s of further calls after all "
+                          "timing; held for 10 s: tools/clock_probe.sh"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,6 +324,20 @@ def main():
         ms_tot += ms
         n_launch += n
     ctx.set_option(pocs_amd.OPT_PROFILE, 0)
+    # shader clock under this load, in calls of their own: a sensor read goes through the driver and
+    # disturbs the GPU (kernels 15 % slower while it polls), so nothing else is measured meanwhile
+    board = None
+    if rank == 0 and not sharded and os.environ.get("POCS_NO_BOARD_PROBE") != "1":
+        try:
+            bus = getattr(torch.cuda.get_device_properties(local), "pci_bus_id", None)
+            probe = BoardProbe("%02x:00.0" % bus if isinstance(bus, int) else None)
+            probe.start()
+            t_end = time.perf_counter() + 0.4
+            while time.perf_counter() < t_end:
+                run_steps([b_hi])
+            board = probe.stop()
+        except Exception:                            # never let the side measurement break the bench line
+            board = None
     kern = "k_gmm_step" if path == "gmm" else ("k_mc_fused" if args.mc_fused else "k_mc_step")
     bpe = BYTES_PER_EVAL_GMM if path == "gmm" else BYTES_PER_EVAL_MC
     avg_ms = ms_tot / max(n_launch, 1)
@@ -284,8 +362,11 @@ def main():
                 rec["bytes_per_launch"] / rec["evals_per_launch"], rec["evals_per_launch"], rec["source"].split(":")[0], units)
     copy_gbps = ctx.copy_bandwidth(1 << 30)       # measured streaming-copy ceiling of this GPU, same process
     fill_gbps = ctx.fill_bandwidth(1 << 30)       # ... and the write-only one (the GMM kernels read nothing)
-    roofline = {"bound": "hbm", "limiter": "FP64 VALU issue, not bandwidth: the SIMDs issue ~100 % of the time at ~210 vector instructions "
-                                           "per evaluation (profiles/r02_*_pmc.txt); the HBM fraction below is what that arithmetic reaches",
+    roofline = {"bound": "hbm", "limiter": ("FP64 VALU issue under the board's power cap, not bandwidth: ~190 vector instructions per evaluation "
+                                           "(profiles/r02_*_pmc.txt) keep the SIMDs issuing ~100 % of the time, and the kernel draws the "
+                                           "1.4 kW cap at a shader clock of ~2.0 of 2.4 GHz (`board`, sampled live); the HBM fraction below is what "
+                                           "that arithmetic reaches" if path == "gmm" else "HBM streaming (MC particle state read and written per waypoint)"),
+                "board": board,
                 "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "copy_GBps": copy_gbps, "frac_of_copy": achieved / copy_gbps if copy_gbps > 0 else None,
