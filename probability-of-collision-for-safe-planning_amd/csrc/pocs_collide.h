@@ -31,7 +31,7 @@ POCS_HD void pocs_prepare_obstacle(const double box5[5], const pocs_footprint* f
 
 // Narrow phase: footprint at (px, py) with heading (sn, cs) against one obstacle record that has
 // passed the broad phase.  Separating axes = the four face normals; a > b <=> a - b > 0 exactly
-// in IEEE arithmetic (gradual underflow), so the four tests fold into one compare of the largest
+// in IEEE arithmetic (gradual underflow), so each pair of tests folds into one compare of the larger
 // margin.  An axis-aligned obstacle (axis exactly (1, 0)) takes a shorter path that produces the
 // same values: fma(c, 1, s*0) == c, fma(dx, 1, dy*0) == dx.
 POCS_HD bool pocs_box_narrow(double px, double py, double sn, double cs, double rx, double ry,
@@ -48,13 +48,20 @@ POCS_HD bool pocs_box_narrow(double px, double py, double sn, double cs, double 
     e1 = fma(dx, ax, dy * ay);                                    // d in the obstacle frame
     e2 = fma(dy, ax, -(dx * ay));
   }
+  // The obstacle's own two axes first: they separate nearly every pose that is in reach but does not
+  // touch (a wall and a robot driving past it), and a wave whose poses are all separated there skips
+  // the footprint's axes.  (max of the four margins > 0  <=>  one of the two maxima > 0.)
+  const double m3 = fabs(e1) - (hx + fma(rx, acr, ry * asr));
+  const double m4 = fabs(e2) - (hy + fma(rx, asr, ry * acr));
+  if (fmax(m3, m4) > 0.0) return false;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("; footprint axes");                                // keeps the early return a branch
+#endif
   const double d1 = fma(dx, cs, dy * sn);                         // d in the footprint frame
   const double d2 = fma(dy, cs, -(dx * sn));
   const double m1 = fabs(d1) - (rx + fma(hx, acr, hy * asr));
   const double m2 = fabs(d2) - (ry + fma(hx, asr, hy * acr));
-  const double m3 = fabs(e1) - (hx + fma(rx, acr, ry * asr));
-  const double m4 = fabs(e2) - (hy + fma(rx, asr, ry * acr));
-  return !(fmax(fmax(m1, m2), fmax(m3, m4)) > 0.0);
+  return !(fmax(m1, m2) > 0.0);
 }
 
 // Broad phase + narrow phase against one record (host-side convenience, same result).
