@@ -17,6 +17,7 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <map>
 
 #include "../../include/pocs.h"
 #include "pocs_kernels.h"
@@ -549,6 +550,80 @@ int gmm_upload_run(pocs_ctx* c) {
   return POCS_OK;
 }
 
+#if defined(POCS_STEP_STAMPS)
+// diagnostic build: one stamp buffer for the process, summarised on stderr after every whole-run call
+static unsigned long long* g_step_dbg = nullptr;
+static size_t g_step_dbg_words = 0;
+static void step_stamps_report(pocs_ctx* c, long long count) {
+  const GmmGeometry geo = gmm_geometry(count, c->batch, c->K);
+  const int W = c->W, R = c->batch, S = geo.slices;
+  std::vector<unsigned long long> h((size_t)W * R * S * 32);
+  if (hipMemcpy(h.data(), g_step_dbg, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  double head = 0, body = 0, spread = 0, ticket = 0, close = 0, adv = 0, total = 0, skew = 0;
+  for (int w = 0; w < W; ++w) {
+    unsigned long long t0 = ~0ull, s0max = 0, s1min = ~0ull, s2max = 0, s3max = 0, s4max = 0, s5max = 0;
+    double s2sum = 0, bsum = 0;
+    for (int b = 0; b < R * S; ++b) {
+      const unsigned long long* q = &h[((size_t)w * R * S + b) * 32];
+      t0 = std::min(t0, q[0]); s0max = std::max(s0max, q[0]); s1min = std::min(s1min, q[1]); s2max = std::max(s2max, q[2]);
+      s3max = std::max(s3max, q[3]); s4max = std::max(s4max, q[4]); s5max = std::max(s5max, q[5]);
+      s2sum += (double)(q[2] - t0 > (1ull << 40) ? 0 : q[2]); bsum += (double)(q[2] - q[1]);
+    }
+    const double mean2 = s2sum / (R * S);
+    skew += (s0max - t0) * 0.01; head += (s1min - t0) * 0.01; body += bsum / (R * S) * 0.01; spread += ((double)s2max - mean2) * 0.01;
+    ticket += (s3max - s2max) * 0.01; close += (s4max > s3max ? (s4max - s3max) * 0.01 : 0); adv += (s5max > s4max ? (s5max - s4max) * 0.01 : 0);
+    total += ((w + 1 < W ? s5max : s3max) - t0) * 0.01;
+  }
+  {   // one waypoint in detail: every block's phases, and the body time by XCD / CU
+    const int w = W / 2;
+    double b1 = 0, dr = 0, tk = 0;
+    std::map<int, std::pair<double, int>> by_xcc, by_cu;
+    std::vector<double> bodies;
+    for (int b = 0; b < R * S; ++b) {
+      const unsigned long long* q = &h[((size_t)w * R * S + b) * 32];
+      b1 += (q[6] - q[2]) * 0.01; dr += (q[7] - q[6]) * 0.01; tk += (q[3] - q[7]) * 0.01;
+      const double body = (q[2] - q[1]) * 0.01;
+      bodies.push_back(body);
+      const int xcc = (int)(q[9] & 15), cu = (int)((q[8] >> 8) & 15), se = (int)((q[8] >> 13) & 7);
+      by_xcc[xcc].first += body; by_xcc[xcc].second++;
+      by_cu[se * 16 + cu].first += body; by_cu[se * 16 + cu].second++;
+    }
+    {   // the block's eight waves: when each finished its body (after the block's body start), by wave index and by SIMD
+      double by_wave[8] = {0}, by_simd[4] = {0}, first_last = 0; int n_simd[4] = {0}; int simd_of[8] = {0};
+      double by_half[2] = {0}; int n_half[2] = {0};
+      for (int b = 0; b < R * S; ++b) {
+        const unsigned long long* q = &h[((size_t)w * R * S + b) * 32];
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int v = 0; v < 8; ++v) {
+          const double t = (q[10 + v] - q[1]) * 0.01;
+          by_wave[v] += t; const int sd = (int)((q[18 + v] >> 4) & 3); by_simd[sd] += t; n_simd[sd]++; if (b == 0) simd_of[v] = sd;
+          lo = std::min(lo, q[10 + v]); hi = std::max(hi, q[10 + v]);
+        }
+        first_last += (hi - lo) * 0.01;
+        by_half[(b >> 8) & 1] += (hi - q[1]) * 0.01; n_half[(b >> 8) & 1]++;
+      }
+      fprintf(stderr, "[step stamps]   a block's waves, body end after body start (us), by wave:");
+      for (int v = 0; v < 8; ++v) fprintf(stderr, " w%d(simd %d) %.1f", v, simd_of[v], by_wave[v] / (R * S));
+      fprintf(stderr, " | by SIMD:");
+      for (int sd = 0; sd < 4; ++sd) fprintf(stderr, " %.1f", by_simd[sd] / std::max(n_simd[sd], 1));
+      fprintf(stderr, " | first -> last wave of a block %.2f | slowest wave, blocks 0-255: %.1f, blocks 256-511: %.1f\n", first_last / (R * S),
+              by_half[0] / std::max(n_half[0], 1), by_half[1] / std::max(n_half[1], 1));
+    }
+    std::sort(bodies.begin(), bodies.end());
+    fprintf(stderr, "[step stamps] waypoint %d: wave 0 body end -> block barrier %.2f us | row + drain + barrier %.2f | ticket + barrier %.2f | body min %.1f p10 %.1f median %.1f p90 %.1f max %.1f\n",
+            w, b1 / (R * S), dr / (R * S), tk / (R * S), bodies.front(), bodies[bodies.size() / 10], bodies[bodies.size() / 2], bodies[bodies.size() * 9 / 10], bodies.back());
+    fprintf(stderr, "[step stamps]   body by XCD:");
+    for (auto& kv : by_xcc) fprintf(stderr, " %d: %.1f (%d)", kv.first, kv.second.first / kv.second.second, kv.second.second);
+    fprintf(stderr, "\n[step stamps]   body by SE.CU:");
+    for (auto& kv : by_cu) fprintf(stderr, " %d.%d: %.1f (%d)", kv.first / 16, kv.first % 16, kv.second.first / kv.second.second, kv.second.second);
+    fprintf(stderr, "\n");
+  }
+  fprintf(stderr, "[step stamps] R=%d S=%d per waypoint (us): start skew %.2f | head (first body start) %.2f | body mean %.2f | last body end - mean %.2f | "
+          "-> all tickets %.2f | close_sums %.2f | advance %.2f | first start -> last stamp %.2f\n",
+          R, S, skew / W, head / W, body / W, spread / W, ticket / W, close / W, adv / W, total / W);
+}
+#endif
+
 void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long count, int w) {
   memset(a, 0, sizeof *a);
   a->hdr = (const pocs_run_header*)c->d_hdr.p;
@@ -571,6 +646,18 @@ void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long
   a->waypoint = w; a->store = c->opt_store ? 1 : 0;
   a->sample_stride = sample_stride_of(count);
   a->nruns = c->batch; a->W = c->W;
+#if defined(POCS_STEP_STAMPS)
+  {
+    const size_t words = (size_t)c->W * c->batch * geo.slices * 32;
+    if (words > g_step_dbg_words) {
+      if (g_step_dbg) (void)hipFree(g_step_dbg);
+      (void)hipMalloc((void**)&g_step_dbg, words * 8);
+      (void)hipMemset(g_step_dbg, 0, words * 8);
+      g_step_dbg_words = words;
+    }
+    a->dbg = g_step_dbg;
+  }
+#endif
 }
 
 // state/param[w] from state/moments[w-1]: its own tiny launch for waypoint 0 and, when sharded,
@@ -717,6 +804,9 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
   gmm_combine(c, (double*)c->h_pin + pin_layout(c).moments, probability);
   c->last_gmm_count = count;
   c->last_gmm_wp = c->W - 1;
+#if defined(POCS_STEP_STAMPS)
+  step_stamps_report(c, count);
+#endif
   return POCS_OK;
 }
 

@@ -77,6 +77,9 @@ struct pocs_gmm_launch {
   // a run = chunks [j*chunks/slices, (j+1)*chunks/slices); task (w, r, j) = slice j of run r at waypoint w
   int slices;
   long long chunks;
+#if defined(POCS_STEP_STAMPS)          // diagnostic build (tools/step_stamps.sh): where a k_gmm_step launch spends its time
+  unsigned long long* dbg;       // [W][nruns][slices][32] wall-clock stamps (100 MHz) of each block
+#endif
 };
 #define POCS_SYNC_HEAD 0
 #define POCS_SYNC_ABORT 1

@@ -528,9 +528,13 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
   // The (up to) four waves of a SIMD -- two of this block, two of the co-resident one -- are arbitrated
   // by priority, then AGE: left alone, the oldest wave of a SIMD runs ~1.7 x faster than the youngest for
   // the whole launch.  Rotating the priority with the iteration gives every wave the same share.
-  // slot = which of the block's waves on this SIMD (waves v and v + TB/256 share one); the second block
-  // of a CU is (observed, speed only) the one dispatched 256 blocks later.
-  const int prio_slot = (TB >= 512 ? __builtin_amdgcn_readfirstlane((tid >> 6) / (TB / 256)) : 0) +
+  // slot = which of the block's waves on this SIMD: wave v runs on SIMD v mod 4, so waves v and v + 4 share
+  // one (HW_ID stamps of a diagnostic build, tools/step_stamps.sh).  The second block of a CU is (observed,
+  // speed only) the one dispatched 256 blocks later.  What the rotation does NOT achieve (same stamps): the
+  // older of a SIMD's waves still win -- a block's waves 4-7 end 3 % after its waves 0-3, the blocks
+  // dispatched second 19 % after the first.  Rotating by the wall clock instead of the iteration count (equal
+  // TIME at each level, no two waves of a SIMD ever tied) measured worse at 2.5 and 5 us per level, +0.8 % at 10.
+  const int prio_slot = (TB >= 512 ? __builtin_amdgcn_readfirstlane((tid >> 6) >> 2) : 0) +
                         (TB >= 512 ? 2 : 1) * (int)(((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 3u);
   int prio_it = prio_slot;
 #endif
@@ -765,6 +769,13 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   __shared__ smem_t sm;
   const int tid = threadIdx.x;
   const int w = a.waypoint, r = blockIdx.y, slot = blockIdx.x;
+#if defined(POCS_STEP_STAMPS)
+  unsigned long long* const dbg_ = a.dbg + (((size_t)w * a.nruns + r) * a.slices + slot) * 32;
+#define POCS_STEP_STAMP(i) do { if (tid == 0) dbg_[i] = wall_clock64(); } while (0)
+#else
+#define POCS_STEP_STAMP(i) do { } while (0)
+#endif
+  POCS_STEP_STAMP(0);
   gmm_stage_static(a, sm);
   for (int j = tid; j < K * POCS_PARAM_STRIDE; j += TB)
     sm.par[0][j] = load_wt(&a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j]);
@@ -774,6 +785,7 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   long long c_begin, c_end;
   gmm_slice_chunks(a, slot, &c_begin, &c_end);
   c_begin = uniform64(c_begin); c_end = uniform64(c_end);      // (64-bit division runs on the vector unit)
+  POCS_STEP_STAMP(1);
 #if defined(POCS_TASK_STAMPS)
   unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
   gmm_body<K, STORE, false, TB>(a, &sm.tab, sm.par[0], sm.keep[0], __builtin_amdgcn_readfirstlane(sm.nkeep[0]), sm.red[0], w, r,
@@ -782,10 +794,19 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   gmm_body<K, STORE, false, TB>(a, &sm.tab, sm.par[0], sm.keep[0], __builtin_amdgcn_readfirstlane(sm.nkeep[0]), sm.red[0], w, r,
                                 a.hdr[r].seed, c_begin, c_end);
 #endif
+  POCS_STEP_STAMP(2);
+#if defined(POCS_STEP_STAMPS)
+  if ((tid & 63) == 0) { dbg_[10 + (tid >> 6)] = wall_clock64(); dbg_[18 + (tid >> 6)] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); }
+#endif
   __syncthreads();
+  POCS_STEP_STAMP(6);
   if (tid < NC) store_wt(&a.partial[((size_t)r * a.slices + slot) * NC + tid], gmm_row_total<NC, RB>(sm.red[0], tid));
   drain_stores();
   __syncthreads();
+  POCS_STEP_STAMP(7);
+#if defined(POCS_STEP_STAMPS)
+  if (tid == 0) { dbg_[8] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); dbg_[9] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); }
+#endif
   if (tid == 0) {
     const unsigned t = __hip_atomic_fetch_add(&a.ticket[(size_t)r * a.W + w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t == (unsigned)a.slices - 1u) ? 1 : 0;
@@ -793,10 +814,14 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
     sm.last = last;
   }
   __syncthreads();
+  POCS_STEP_STAMP(3);
   if (__builtin_amdgcn_readfirstlane(sm.last) == 0) return;
   double* const l_mom = advance_ptrs(a, K, w + 1, r, sm.adv).l_mom;
   gmm_close_sums<K, RB>(a, w, r, sm.par[0], &sm.red[0][0][0], l_mom, tid, TB, [] { __syncthreads(); });
+  POCS_STEP_STAMP(4);
   if (a.advance_in_tail) advance_block(a, K, w + 1, r, sm.adv, sm.spec, true, tid, TB);     // starts with a barrier after staging
+  __syncthreads();
+  POCS_STEP_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------
