@@ -444,30 +444,66 @@ __device__ __forceinline__ void gmm_stage_static(const pocs_gmm_launch& a, gmm_s
 // draw lies within mean_k +- 6.67 (|L00|, |L10|+|L11|) of some component; an obstacle whose inflated
 // box (the broad phase of pocs_box_hit) misses that region is rejected by the broad phase for every
 // sample, so dropping it here changes no flag.
+//
+// The same bound on the heading makes the broad phase of the kept records tighter than the table's: the
+// table inflates an obstacle's box by the footprint's bounding RADIUS (any heading); a task whose
+// headings all lie in [t_lo, t_hi] needs only the footprint's largest half-extent along world x and
+// along world y over that range (two convex sets that touch overlap in every projection).  Where the
+// robot's heading is known to a fraction of a radian -- most of a plan -- far fewer poses reach the
+// narrow phase, and none that could touch is lost: the flags do not change.
+//   f(t) = rx |cos t| + ry |sin t| (world-x half extent; world-y: f(t - pi/2)) is concave between the
+//   multiples of pi/2 and peaks with the bounding radius at t = +-atan(ry / rx) + k pi.
+__device__ __forceinline__ double gmm_footprint_extent(const double rx, const double ry, const double lo, const double hi) {
+  const double rr = sqrt(rx * rx + ry * ry), PI = 3.14159265358979323846;
+  if (!(hi - lo < PI)) return rr;
+  const double phi = atan2(ry, rx);
+  for (int sgn = -1; sgn <= 1; sgn += 2) {
+    const double s = sgn * phi;
+    if (ceil((lo - s) / PI) <= floor((hi - s) / PI)) return rr;         // a peak inside the range
+  }
+  double sn, cs;
+  pocs_sincos(lo, &sn, &cs);
+  const double fa = fma(rx, fabs(cs), ry * fabs(sn));
+  pocs_sincos(hi, &sn, &cs);
+  const double fb = fma(rx, fabs(cs), ry * fabs(sn));
+  return fmin(rr, fmax(fa, fb) * (1.0 + 1e-9) + 1e-12);
+}
+
 template <int K, int TB, int NB>
 __device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, TB, NB>& sm, const int buf, const int lane) {
   const pocs_footprint fp = a.fp;
   const int M = a.M;
-  double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
+  double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300, tlo = 1e300, thi = -1e300;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const double* p = &sm.par[buf][k * POCS_PARAM_STRIDE];
-    const double ex = 6.67 * fabs(p[3]), ey = 6.67 * (fabs(p[4]) + fabs(p[5]));
+    const double ex = 6.67 * fabs(p[3]), ey = 6.67 * (fabs(p[4]) + fabs(p[5])), et = 6.67 * (fabs(p[6]) + fabs(p[7]) + fabs(p[8]));
     xlo = fmin(xlo, p[0] - ex); xhi = fmax(xhi, p[0] + ex);
     ylo = fmin(ylo, p[1] - ey); yhi = fmax(yhi, p[1] + ey);
+    tlo = fmin(tlo, p[2] - et); thi = fmax(thi, p[2] + et);
   }
   const double pad = sqrt(fp.dx * fp.dx + fp.dy * fp.dy) + 1e-6;   // footprint centre vs base
   xlo -= pad; xhi += pad; ylo -= pad; yhi += pad;
+  tlo -= 1e-9 * (1.0 + fabs(tlo)); thi += 1e-9 * (1.0 + fabs(thi));
+  const double HALF_PI = 1.57079632679489661923;
+  const double ext_x = gmm_footprint_extent(fp.hx, fp.hy, tlo, thi);
+  const double ext_y = gmm_footprint_extent(fp.hx, fp.hy, tlo - HALF_PI, thi - HALF_PI);
   bool keep = false;
+  double bx = 0.0, by = 0.0;
   if (lane < M) {
     const double* o = &sm.obs[lane * POCS_OBS_STRIDE];
-    keep = !(o[0] - o[6] > xhi || o[0] + o[6] < xlo || o[1] - o[7] > yhi || o[1] + o[7] < ylo);
+    // the obstacle's own world box (as pocs_prepare_obstacle) + the footprint's extents for this task
+    bx = fmin(o[6], fma(o[4], fabs(o[2]), o[5] * fabs(o[3])) * (1.0 + 1e-12) + ext_x);
+    by = fmin(o[7], fma(o[4], fabs(o[3]), o[5] * fabs(o[2])) * (1.0 + 1e-12) + ext_y);
+    keep = !(o[0] - bx > xhi || o[0] + bx < xlo || o[1] - by > yhi || o[1] + by < ylo);
   }
   const unsigned long long mask = __ballot(keep);
   if (keep) {
     const int pos = __popcll(mask & ((1ull << lane) - 1ull));
 #pragma unroll
-    for (int j = 0; j < POCS_OBS_STRIDE; ++j) sm.keep[buf][pos * POCS_OBS_STRIDE + j] = sm.obs[lane * POCS_OBS_STRIDE + j];
+    for (int j = 0; j < 6; ++j) sm.keep[buf][pos * POCS_OBS_STRIDE + j] = sm.obs[lane * POCS_OBS_STRIDE + j];
+    sm.keep[buf][pos * POCS_OBS_STRIDE + 6] = bx;
+    sm.keep[buf][pos * POCS_OBS_STRIDE + 7] = by;
   }
   if (lane == 0) sm.nkeep[buf] = __popcll(mask);
 }
