@@ -218,7 +218,8 @@ def main():
     # runs and the rest of b_lo runs.
     maxb = args.batch if args.batch > 0 else (64 if path == "gmm" else 8)
     ncalls = (args.steps + maxb - 1) // maxb
-    if sharded and path == "gmm" and args.steps >= 2:
+    fused_exchange = os.environ.get("POCS_ONEHOP") == "2"      # sample + exchange + advance in one launch: ONE engine, as on one GPU
+    if sharded and path == "gmm" and args.steps >= 2 and not fused_exchange:
         # N > 1: an even number of calls, so that two engines are always in flight and one engine's
         # all-reduce is covered by the other's kernel
         ncalls = max(2, ncalls + (ncalls & 1))
@@ -262,13 +263,15 @@ def main():
     else:
         # one rank per GPU: two engines on two streams take the calls in turn, so one engine's
         # kernel runs while the other's moments are in the all-reduce (parallel.run_gmm_pipelined)
-        n_eng = 2 if (path == "gmm" and len(chunks) >= 2) else 1
+        n_eng = 2 if (path == "gmm" and len(chunks) >= 2 and not fused_exchange) else 1
         made = [make(b_hi, 0x5EED0001 + i, torch.cuda.Stream() if n_eng > 1 else None) for i in range(n_eng)]
         ctx = made[0][0]
         engines = [e for _, e in made]
         # POCS_ONEHOP=1: the library's own exchange (IPC-mapped slots, one hop over xGMI, sum + mixture
         # advance in one small launch) instead of one RCCL all-reduce per waypoint from Python
-        onehop = path == "gmm" and os.environ.get("POCS_ONEHOP") == "1"
+        onehop = path == "gmm" and os.environ.get("POCS_ONEHOP") in ("1", "2")
+        # POCS_ONEHOP=2: sample + exchange + advance in ONE launch per waypoint (pocs_gmm_sample_exchange_local)
+        run_onehop = par.run_gmm_onehop_fused if os.environ.get("POCS_ONEHOP") == "2" else par.run_gmm_onehop
         if onehop:
             for e in engines:
                 e.connect_onehop(dist if world > 1 else None, rank, world)
@@ -284,7 +287,7 @@ def main():
                 for e, b in zip(engines, group):
                     if e.batch != b:
                         e.set_batch(b)
-                p = (par.run_gmm_onehop(engines[:len(group)]) if onehop else par.run_gmm_pipelined(engines[:len(group)], dist))[0]
+                p = (run_onehop(engines[:len(group)]) if onehop else par.run_gmm_pipelined(engines[:len(group)], dist))[0]
             return p
 
     def fence():
@@ -315,7 +318,7 @@ def main():
             if engines[0].batch != b_hi:
                 engines[0].set_batch(b_hi)
             if path == "gmm":
-                (par.run_gmm_onehop(engines[:1]) if onehop else par.run_gmm_pipelined(engines[:1], dist))
+                (run_onehop(engines[:1]) if onehop else par.run_gmm_pipelined(engines[:1], dist))
             else:
                 par.run_mc_sharded(engines[0], N, dist)
         else:
@@ -407,7 +410,8 @@ def main():
                        "waypoints": W, "samples_per_gpu": n_local, "components": K, "probability": prob,
                        "runs_per_launch": batch, "calls": chunks,
                        "engines_in_flight": len(engines) if engines else 1,
-                       "exchange": ("one-hop IPC slots (pocs_gmm_exchange_local)" if (sharded and path == "gmm" and os.environ.get("POCS_ONEHOP") == "1")
+                       "exchange": ("one-hop IPC slots in the sampling launch's tail (pocs_gmm_sample_exchange_local)" if (sharded and path == "gmm" and os.environ.get("POCS_ONEHOP") == "2")
+                                    else "one-hop IPC slots (pocs_gmm_exchange_local)" if (sharded and path == "gmm" and os.environ.get("POCS_ONEHOP") == "1")
                                     else "RCCL all-reduce per waypoint" if (sharded and path == "gmm") else "none (one GPU)"),
                        "total_samples_per_run": N,
                        "value_is": "batched throughput: `runs_per_launch` independent runs (the reference driver's 200-run loop) "

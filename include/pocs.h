@@ -128,6 +128,12 @@ int pocs_gmm_end(pocs_ctx* ctx, double* probability);
 int pocs_xchg_create(pocs_ctx* ctx, int world, int rank, void* handle64_out);
 int pocs_xchg_connect(pocs_ctx* ctx, const void* handles_world_x_64, int world);
 int pocs_gmm_exchange_local(pocs_ctx* ctx, int waypoint);
+/* The two in ONE launch (the form bench.py uses with POCS_ONEHOP=1): the block that closes a run's
+ * waypoint is also its messenger -- it sends the shard's moments, waits for the world's, adds them in rank
+ * order and builds the next mixture, while the launch's finished blocks have already given their CUs to
+ * whatever else is queued (a second context's sampling launch).  Per waypoint: sample_exchange_local(w);
+ * before waypoint 0: advance_local(0).  Same results as sample_local + exchange_local, bit for bit. */
+int pocs_gmm_sample_exchange_local(pocs_ctx* ctx, int waypoint);
 /* MC: the shard's count of particles that collided at least once (device-synchronous). */
 int pocs_mc_run_local(pocs_ctx* ctx, unsigned long long* collided);            /* run 0 of the batch */
 int pocs_mc_get_batch_counts(pocs_ctx* ctx, unsigned long long* out, int cap);   /* every run of the last MC batch */

@@ -60,6 +60,7 @@ SIGNATURES = {
     "pocs_xchg_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_void_p]),
     "pocs_xchg_connect": (C.c_int, [_vp, C.c_void_p, C.c_int]),
     "pocs_gmm_exchange_local": (C.c_int, [_vp, C.c_int]),
+    "pocs_gmm_sample_exchange_local": (C.c_int, [_vp, C.c_int]),
     "pocs_get_path_length": (C.c_int, [_vp]),
     "pocs_get_waypoint_probabilities": (C.c_int, [_vp, _dp, C.c_int]),
     "pocs_get_moments": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
@@ -310,6 +311,10 @@ class Context:
 
     def gmm_exchange_local(self, w):
         self._chk(self.lib.pocs_gmm_exchange_local(self.h, w))
+
+    def gmm_sample_exchange_local(self, w):
+        """sample(w) and exchange(w) in one launch (include/pocs.h)."""
+        self._chk(self.lib.pocs_gmm_sample_exchange_local(self.h, w))
 
     def gmm_moments_ptr(self, w):
         return self.lib.pocs_gmm_moments_ptr(self.h, w)

@@ -1344,8 +1344,12 @@ int pocs_xchg_create(pocs_ctx* c, int world, int rank, void* handle64) {
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "pocs.h promises a 64-byte handle");
   HIPCHK(c, hipSetDevice(c->device));
   if (!c->xchg_own) {
-    HIPCHK(c, hipMalloc(&c->xchg_own, POCS_XCHG_BYTES));
+    // FINE-GRAINED device memory: other GPUs write into it and this GPU polls it inside a running kernel.
+    // Ordinary (coarse-grained) allocations are only coherent with other devices at kernel boundaries --
+    // a flag once cached in an XCD's L2 could be read stale for ever.
+    HIPCHK(c, hipExtMallocWithFlags(&c->xchg_own, POCS_XCHG_BYTES, hipDeviceMallocFinegrained));
     HIPCHK(c, hipMemset(c->xchg_own, 0, POCS_XCHG_BYTES));       // epoch 0 = nothing has landed
+    HIPCHK(c, hipDeviceSynchronize());
   }
   c->xchg_world = world; c->xchg_rank = rank; c->xchg_connected = false;
   hipIpcMemHandle_t h;
@@ -1384,6 +1388,35 @@ int pocs_gmm_exchange_local(pocs_ctx* c, int w) {
   x.epoch = (c->xchg_calls << 20) | (unsigned long long)(w + 1);
   HIPCHK(c, pocs_launch_gmm_exchange(c->K, a, x, c->stream));
   if (w + 1 < c->W) c->last_gmm_adv = w + 1;          // the exchange launch has built the mixture of w + 1
+  return POCS_OK;
+}
+
+// sample(w) + exchange(w) in ONE launch: the block that closes a run's waypoint exchanges its moments
+// (k_gmm_step, exchange_in_tail) and advances the mixture -- what pocs_gmm_sample_local followed by
+// pocs_gmm_exchange_local does with two launches, bit for bit.
+int pocs_gmm_sample_exchange_local(pocs_ctx* c, int w) {
+  if (!c) return POCS_E_ARG;
+  if (!c->gmm_open) return fail(c, POCS_E_ORDER, "pocs_gmm_sample_exchange_local before pocs_gmm_begin");
+  if (!c->xchg_connected) return fail(c, POCS_E_ORDER, "pocs_gmm_sample_exchange_local before pocs_xchg_connect");
+  if (w != c->last_gmm_wp + 1 || w >= c->W) return fail(c, POCS_E_ORDER, "waypoint %d out of sequence", w);
+  if (w != c->last_gmm_adv) return fail(c, POCS_E_ORDER, "waypoint %d sampled before its mixture exists", w);
+  if (c->batch > POCS_XCHG_MAX_RUNS) return fail(c, POCS_E_ARG, "exchange: at most %d runs per call", POCS_XCHG_MAX_RUNS);
+  long long first, count;
+  if (int r = gmm_shard(c, &first, &count)) return r;
+  pocs_gmm_launch a;
+  fill_gmm_launch(c, &a, first, count, w);
+  a.advance_in_tail = (w + 1 < c->W) ? 1 : 0;
+  a.exchange_in_tail = 1;
+  for (int q = 0; q < c->xchg_world; ++q) a.xchg.buf[q] = (double*)c->xchg_peer[q];
+  a.xchg.world = c->xchg_world; a.xchg.rank = c->xchg_rank;
+  a.xchg.epoch = (c->xchg_calls << 20) | (unsigned long long)(w + 1);
+  const int slot = c->opt_profile ? w : -1;
+  if (slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * slot], c->stream));
+  HIPCHK(c, pocs_launch_gmm_step(c->K, a, c->stream));
+  if (slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * slot + 1], c->stream));
+  c->last_gmm_wp = w;
+  c->last_gmm_count = count;
+  if (w + 1 < c->W) c->last_gmm_adv = w + 1;
   return POCS_OK;
 }
 

@@ -44,6 +44,23 @@ struct pocs_run_header {         // per-run scalars read by every kernel (so a c
   uint64_t pad;
 };
 
+// One-hop exchange of the per-waypoint moments between the GPUs of a node (SURVEY section 5): every rank
+// owns a buffer that ALL ranks have mapped (hipIpc); rank q writes its rows into slot q of every
+// buffer, then its flags; every rank adds the slots of its own buffer in rank order.
+//   data  f64 [2 parities][POCS_XCHG_MAX_WORLD][POCS_XCHG_MAX_RUNS][POCS_XCHG_MAX_NC]
+//   flags u64 [2 parities][POCS_XCHG_MAX_WORLD][POCS_XCHG_MAX_RUNS]      = epoch of the row in that slot
+#define POCS_XCHG_MAX_WORLD 8
+#define POCS_XCHG_MAX_RUNS 256
+#define POCS_XCHG_MAX_NC (POCS_MAX_GAUSSIANS * POCS_NMOM)
+#define POCS_XCHG_DATA_DOUBLES (2ull * POCS_XCHG_MAX_WORLD * POCS_XCHG_MAX_RUNS * POCS_XCHG_MAX_NC)
+#define POCS_XCHG_FLAG_WORDS (2ull * POCS_XCHG_MAX_WORLD * POCS_XCHG_MAX_RUNS)
+#define POCS_XCHG_BYTES ((POCS_XCHG_DATA_DOUBLES + POCS_XCHG_FLAG_WORDS + 2) * 8ull)
+struct pocs_xchg_dev {
+  double* buf[POCS_XCHG_MAX_WORLD];   // buffer of rank q as mapped in THIS process (own rank: the allocation itself)
+  int world, rank;
+  unsigned long long epoch;           // of this waypoint's rows: (call number << 20) | (waypoint + 1)
+};
+
 // Arrays carry a leading "run" dimension: a launch advances `nruns` independent estimations (the
 // reference's driver performs 200 of them one after the other, MCSimulation.py:238-256) in lockstep.
 struct pocs_gmm_launch {
@@ -73,6 +90,8 @@ struct pocs_gmm_launch {
   int waypoint;
   int store;
   int advance_in_tail;           // 1: the last block also builds state/param[waypoint+1] (single GPU)
+  int exchange_in_tail;          // 1: ... after exchanging the run's moments with the other ranks through `xchg` (sharded)
+  pocs_xchg_dev xchg;
   // task geometry: a chunk = POCS_GMM_BLOCK_OF(K) pairs of samples (one iteration of a block); slice j of
   // a run = chunks [j*chunks/slices, (j+1)*chunks/slices); task (w, r, j) = slice j of run r at waypoint w
   int slices;
@@ -103,22 +122,6 @@ struct pocs_mc_launch {               // blockIdx.y = run of the batch, like poc
   int nontemporal;                     // k_mc_step: the batch's state exceeds the Infinity Cache, stream past it
 };
 
-// One-hop exchange of the per-waypoint moments between the GPUs of a node (SURVEY section 5): every rank
-// owns a buffer that ALL ranks have mapped (hipIpc); rank q writes its rows into slot q of every
-// buffer, then its flags; every rank adds the slots of its own buffer in rank order.
-//   data  f64 [2 parities][POCS_XCHG_MAX_WORLD][POCS_XCHG_MAX_RUNS][POCS_XCHG_MAX_NC]
-//   flags u64 [2 parities][POCS_XCHG_MAX_WORLD][POCS_XCHG_MAX_RUNS]      = epoch of the row in that slot
-#define POCS_XCHG_MAX_WORLD 8
-#define POCS_XCHG_MAX_RUNS 256
-#define POCS_XCHG_MAX_NC (POCS_MAX_GAUSSIANS * POCS_NMOM)
-#define POCS_XCHG_DATA_DOUBLES (2ull * POCS_XCHG_MAX_WORLD * POCS_XCHG_MAX_RUNS * POCS_XCHG_MAX_NC)
-#define POCS_XCHG_FLAG_WORDS (2ull * POCS_XCHG_MAX_WORLD * POCS_XCHG_MAX_RUNS)
-#define POCS_XCHG_BYTES ((POCS_XCHG_DATA_DOUBLES + POCS_XCHG_FLAG_WORDS + 2) * 8ull)
-struct pocs_xchg_dev {
-  double* buf[POCS_XCHG_MAX_WORLD];   // buffer of rank q as mapped in THIS process (own rank: the allocation itself)
-  int world, rank;
-  unsigned long long epoch;           // of this waypoint's rows: (call number << 20) | (waypoint + 1)
-};
 
 hipError_t pocs_launch_gmm_step(int K, const pocs_gmm_launch& a, hipStream_t s);              // grid = (a.slices, a.nruns)
 hipError_t pocs_launch_gmm_run(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);    // persistent: all W waypoints

@@ -362,27 +362,27 @@ __device__ __forceinline__ unsigned long long* xchg_flag(double* buf, int parity
   return reinterpret_cast<unsigned long long*>(buf + POCS_XCHG_DATA_DOUBLES) +
          ((size_t)parity * POCS_XCHG_MAX_WORLD + src) * POCS_XCHG_MAX_RUNS + r;
 }
-__global__ __launch_bounds__(128) void k_gmm_exchange(pocs_gmm_launch a, pocs_xchg_dev x, int K) {
-  __shared__ double s_adv[POCS_ADV_SCRATCH(POCS_MAX_GAUSSIANS)];
-  __shared__ double s_spec[POCS_SPEC_SCRATCH(POCS_MAX_GAUSSIANS)];
-  __shared__ int s_ok;
-  const int tid = threadIdx.x, r = blockIdx.x, w = a.waypoint, NC = K * POCS_NMOM, parity = w & 1;
-  // an earlier exchange of this call gave up: do not wait another 5 s per waypoint, the call is lost
-  if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-  // my row -> slot `rank` of every rank's buffer
-  const double* mine = a.moments + ((size_t)w * a.nruns + r) * NC;
-  for (int i = tid; i < NC * x.world; i += 128) {
+// The exchange itself, by the `nthreads` threads of one block for run r at waypoint w: `mine` (NC doubles,
+// global or LDS) -> slot `rank` of every rank's buffer; wait for the world's rows; the sum in rank order
+// -> a.moments[w][r] and l_mom (LDS; may be `mine`).  s_ok: one int of LDS.  false = gave up.
+__device__ __forceinline__ bool gmm_exchange_rows(const pocs_gmm_launch& a, const pocs_xchg_dev& x, const int K, const int w, const int r,
+                                                  const double* mine, double* l_mom, const int tid, const int nthreads, int* s_ok) {
+  const int NC = K * POCS_NMOM, parity = w & 1;
+  for (int i = tid; i < NC * x.world; i += nthreads) {
     const int q = i / NC, c = i - q * NC;
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(xchg_row(x.buf[q], parity, x.rank, r) + c),
                        (unsigned long long)__double_as_longlong(mine[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: the rows are out before the flags
+  // the rows are out before the flags: they were stored write-through at system scope, and every storing
+  // wave waits for its stores here.  (NOT a system-scope release fence: that writes back the whole L2, and
+  // in the tail of a sampling launch the L2 is full of samples on their way out -- measured +45 us per
+  // 64-run launch.)
   drain_stores();
   __syncthreads();
   if (tid < x.world)
     __hip_atomic_store(xchg_flag(x.buf[tid], parity, x.rank, r), x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // every rank's row of this waypoint has landed in MY buffer?
-  if (tid == 0) s_ok = 1;
+  if (tid == 0) *s_ok = 1;
   __syncthreads();
   if (tid < x.world) {
     const unsigned long long* f = xchg_flag(x.buf[x.rank], parity, tid, r);
@@ -392,17 +392,19 @@ __global__ __launch_bounds__(128) void k_gmm_exchange(pocs_gmm_launch a, pocs_xc
       __builtin_amdgcn_s_sleep(8);
       if ((++polls & 255u) == 0u && wall_clock64() - t0 > 3000000000ull) {      // 30 s: ranks of a cold node start seconds apart
         __hip_atomic_store(&a.sync[POCS_SYNC_ABORT], 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_ok = 0;
+        *s_ok = 0;
         break;
       }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");            // system scope
+  if (tid < 64) {                                          // ONE wave, the one that polled: drop this XCD's stale lines
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // system scope
+    drain_stores();                                        // the invalidate completes before the barrier releases the readers
+  }
   __syncthreads();
-  if (!s_ok) return;
+  if (!*s_ok) return false;
   // the slots of my buffer, added in rank order
-  double* const l_mom = advance_ptrs(a, K, w + 1, r, s_adv).l_mom;
-  for (int c = tid; c < NC; c += 128) {
+  for (int c = tid; c < NC; c += nthreads) {
     double tot = 0.0;
     for (int q = 0; q < x.world; ++q)
       tot += __longlong_as_double((long long)__hip_atomic_load(
@@ -410,6 +412,17 @@ __global__ __launch_bounds__(128) void k_gmm_exchange(pocs_gmm_launch a, pocs_xc
     a.moments[((size_t)w * a.nruns + r) * NC + c] = tot;    // the mixture's moments replace this shard's
     l_mom[c] = tot;
   }
+  return true;
+}
+__global__ __launch_bounds__(128) void k_gmm_exchange(pocs_gmm_launch a, pocs_xchg_dev x, int K) {
+  __shared__ double s_adv[POCS_ADV_SCRATCH(POCS_MAX_GAUSSIANS)];
+  __shared__ double s_spec[POCS_SPEC_SCRATCH(POCS_MAX_GAUSSIANS)];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, r = blockIdx.x, w = a.waypoint, NC = K * POCS_NMOM;
+  // an earlier exchange of this call gave up: do not wait another 30 s per waypoint, the call is lost
+  if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+  double* const l_mom = advance_ptrs(a, K, w + 1, r, s_adv).l_mom;
+  if (!gmm_exchange_rows(a, x, K, w, r, a.moments + ((size_t)w * a.nruns + r) * NC, l_mom, tid, 128, &s_ok)) return;
   if (w + 1 < a.W) advance_block(a, K, w + 1, r, s_adv, s_spec, true, tid, 128);     // starts with a barrier after staging
 }
 
@@ -855,6 +868,14 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   double* const l_mom = advance_ptrs(a, K, w + 1, r, sm.adv).l_mom;
   gmm_close_sums<K, RB>(a, w, r, sm.par[0], &sm.red[0][0][0], l_mom, tid, TB, [] { __syncthreads(); });
   POCS_STEP_STAMP(4);
+  if (a.exchange_in_tail) {
+    // sharded: the run's closer is also its messenger -- this shard's moments go to every rank, the world's
+    // come back summed in rank order, and the mixture advances here; meanwhile the other engine's sampling
+    // launch has the CUs this launch's finished blocks gave back (no launch, no host, between waypoints)
+    __syncthreads();
+    if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    if (!gmm_exchange_rows(a, a.xchg, K, w, r, l_mom, l_mom, tid, TB, &sm.last)) return;
+  }
   if (a.advance_in_tail) advance_block(a, K, w + 1, r, sm.adv, sm.spec, true, tid, TB);     // starts with a barrier after staging
   __syncthreads();
   POCS_STEP_STAMP(5);

@@ -72,6 +72,33 @@ def run_gmm_onehop(engines):
     return out
 
 
+def run_gmm_onehop_fused(engines):
+    """run_gmm_onehop with ONE launch per waypoint and engine (pocs_gmm_sample_exchange_local): the block
+    that closes a run's waypoint exchanges its moments and advances the mixture in the sampling launch's
+    tail.  Nothing orders the two engines' launches except, once, the start: the second engine's first
+    launch waits for the first engine's -- from then on each engine's next launch becomes ready while the
+    other's blocks hold the CUs and takes them as they finish, so an engine's exchange (its closers wait
+    for the other ranks) always runs beside the other engine's sampling."""
+    first = None
+    for e in engines:
+        with e.stream_ctx():
+            e.begin()
+            e.advance(0)
+    for w in range(engines[0].W):
+        for i, e in enumerate(engines):
+            with e.stream_ctx():
+                if w == 0 and i > 0 and first is not None:
+                    e.wait_event(first)
+                e.sample_exchange(w)
+                if w == 0 and i == 0:
+                    first = e.record_event()
+    out = []
+    for e in engines:
+        with e.stream_ctx():
+            out.append(e.end())
+    return out
+
+
 def run_gmm_pipelined(engines, dist):
     """Two (or more) engines, each with its own batch of runs and its own stream, advanced waypoint
     by waypoint in turn: while one engine's moments are in the all-reduce (and its small mixture
@@ -175,6 +202,9 @@ class GpuEngine:
 
     def exchange(self, w):
         self.ctx.gmm_exchange_local(w)
+
+    def sample_exchange(self, w):
+        self.ctx.gmm_sample_exchange_local(w)
 
     def moments(self, w):
         n = self.batch * self.K * 11           # one exchange per waypoint covers every run of the batch

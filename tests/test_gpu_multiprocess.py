@@ -60,12 +60,15 @@ def _worker_onehop(rank, world, port, n_local, K, seed, batch, out):
     plan, env = pocs_amd.load_plan(), pocs_amd.load_env()
     N = n_local * world
     res = {}
-    for mode in ("gloo", "onehop", "onehop_again"):
+    for mode in ("gloo", "onehop", "onehop_again", "fused"):
         c = pocs_amd.Context(0)
         c.configure(plan, env, K=K, N=N, seed=seed)
         e = par.GpuEngine(c, 56, K, N, rank=rank, world=world, per_rank=n_local, batch=batch, stream=torch.cuda.Stream())
         if mode == "gloo":
             par.run_gmm_pipelined([e], dist)
+        elif mode == "fused":                             # sample + exchange + advance in one launch per waypoint
+            e.connect_onehop(dist, rank, world)
+            par.run_gmm_onehop_fused([e])
         else:
             e.connect_onehop(dist, rank, world)
             par.run_gmm_onehop([e])
@@ -77,7 +80,7 @@ def _worker_onehop(rank, world, port, n_local, K, seed, batch, out):
         c.close()
     if rank == 0:
         np.savez(out, p_gloo=res["gloo"][0], p_one=res["onehop"][0], m_gloo=res["gloo"][1], m_one=res["onehop"][1],
-                 p_again=res["onehop_again"][0])
+                 p_again=res["onehop_again"][0], p_fused=res["fused"][0], m_fused=res["fused"][1])
     dist.destroy_process_group()
 
 
@@ -94,6 +97,8 @@ def test_onehop_exchange_equals_the_collective(tmp_path, pocs, plan, env):
     assert list(got["p_one"]) == list(got["p_gloo"])
     assert np.array_equal(got["m_one"], got["m_gloo"])
     assert list(got["p_again"]) != list(got["p_one"]) and all(0 < p < 1 for p in got["p_again"])
+    # the exchange in the sampling launch's tail: the same bits again
+    assert list(got["p_fused"]) == list(got["p_gloo"]) and np.array_equal(got["m_fused"], got["m_gloo"])
     with pocs.Context(0) as c:                              # and both equal one process on the whole mixture
         c.configure(plan, env, K=K, N=2 * n_local, seed=seed)
         c.set_batch(batch)
