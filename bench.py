@@ -154,6 +154,38 @@ class BoardProbe:
                           "timing; held for 10 s: tools/clock_probe.sh"}
 
 
+def probe_onehop(par, pocs_amd, torch, dist, rank, world, local):
+    """One small sharded GMM call through the library's IPC exchange (pocs_gmm_sample_exchange_local) on
+    this node: True if it ran on every rank and every rank got the same probability.  A node where peer
+    mapping or in-kernel peer traffic does not work shows here (an exception, or the kernel's bounded wait
+    giving up after 30 s), before anything is timed."""
+    ok, p = 1, -1.0
+    ctx = None
+    try:
+        plan, env = pocs_amd.load_plan(), pocs_amd.load_env()
+        ctx = pocs_amd.Context(local)
+        ctx.configure(plan, env, K=3, N=8192 * world, seed=0x5EED00AA)
+        e = par.GpuEngine(ctx, len(plan["traj"]), 3, 8192 * world, rank=rank, world=world, per_rank=8192, batch=2)
+        e.connect_onehop(dist, rank, world)
+        p = par.run_gmm_onehop_fused([e])[0]
+        torch.cuda.synchronize()
+    except Exception as exc:                           # noqa: BLE001 -- whatever it is, the other path is taken
+        print("one-hop probe: %s" % exc, file=sys.stderr)
+        ok = 0
+    finally:
+        if ctx is not None:
+            try:
+                ctx.close()
+            except Exception:                          # noqa: BLE001
+                pass
+    if dist is not None:
+        t = torch.tensor([float(ok), p, -p], dtype=torch.float64,
+                         device="cuda" if os.environ.get("POCS_DIST_BACKEND", "nccl") == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)       # min ok, min p, -max p
+        ok = int(t[0].item()) and (t[1].item() == -t[2].item())
+    return bool(ok)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,7 +250,18 @@ def main():
     # runs and the rest of b_lo runs.
     maxb = args.batch if args.batch > 0 else (64 if path == "gmm" else 8)
     ncalls = (args.steps + maxb - 1) // maxb
-    fused_exchange = os.environ.get("POCS_ONEHOP") == "2"      # sample + exchange + advance in one launch: ONE engine, as on one GPU
+    # How the shards of the GMM path exchange their moments (POCS_ONEHOP): "2" = the library's one-hop
+    # exchange in the sampling launch's tail (one launch per waypoint, ONE engine, as on one GPU; the
+    # default for N > 1, after a small end-to-end probe of it on this node has succeeded on every rank),
+    # "1" = the one-hop exchange as its own launch, "0" = one RCCL all-reduce per waypoint (two engines).
+    xmode = os.environ.get("POCS_ONEHOP", "2" if (sharded and WORKLOADS[args.workload][3] == "gmm") else "0")
+    xnote = None
+    if sharded and xmode == "2" and "POCS_ONEHOP" not in os.environ:
+        ok = probe_onehop(par, pocs_amd, torch, dist if world > 1 else None, rank, world, local)
+        if not ok:
+            xmode, xnote = "0", "one-hop probe failed on this node: fell back to RCCL"
+    os.environ["POCS_ONEHOP"] = xmode
+    fused_exchange = xmode == "2"
     if sharded and path == "gmm" and args.steps >= 2 and not fused_exchange:
         # N > 1: an even number of calls, so that two engines are always in flight and one engine's
         # all-reduce is covered by the other's kernel
@@ -269,9 +312,8 @@ def main():
         engines = [e for _, e in made]
         # POCS_ONEHOP=1: the library's own exchange (IPC-mapped slots, one hop over xGMI, sum + mixture
         # advance in one small launch) instead of one RCCL all-reduce per waypoint from Python
-        onehop = path == "gmm" and os.environ.get("POCS_ONEHOP") in ("1", "2")
-        # POCS_ONEHOP=2: sample + exchange + advance in ONE launch per waypoint (pocs_gmm_sample_exchange_local)
-        run_onehop = par.run_gmm_onehop_fused if os.environ.get("POCS_ONEHOP") == "2" else par.run_gmm_onehop
+        onehop = path == "gmm" and xmode in ("1", "2")
+        run_onehop = par.run_gmm_onehop_fused if xmode == "2" else par.run_gmm_onehop
         if onehop:
             for e in engines:
                 e.connect_onehop(dist if world > 1 else None, rank, world)
@@ -410,9 +452,9 @@ def main():
                        "waypoints": W, "samples_per_gpu": n_local, "components": K, "probability": prob,
                        "runs_per_launch": batch, "calls": chunks,
                        "engines_in_flight": len(engines) if engines else 1,
-                       "exchange": ("one-hop IPC slots in the sampling launch's tail (pocs_gmm_sample_exchange_local)" if (sharded and path == "gmm" and os.environ.get("POCS_ONEHOP") == "2")
-                                    else "one-hop IPC slots (pocs_gmm_exchange_local)" if (sharded and path == "gmm" and os.environ.get("POCS_ONEHOP") == "1")
-                                    else "RCCL all-reduce per waypoint" if (sharded and path == "gmm") else "none (one GPU)"),
+                       "exchange": ("one-hop IPC slots in the sampling launch's tail (pocs_gmm_sample_exchange_local)" if (sharded and path == "gmm" and xmode == "2")
+                                    else "one-hop IPC slots (pocs_gmm_exchange_local)" if (sharded and path == "gmm" and xmode == "1")
+                                    else ("RCCL all-reduce per waypoint" + (" (%s)" % xnote if xnote else "")) if (sharded and path == "gmm") else "none (one GPU)"),
                        "total_samples_per_run": N,
                        "value_is": "batched throughput: `runs_per_launch` independent runs (the reference driver's 200-run loop) "
                                    "advance in lockstep per call; single_call_evals_per_s = one run per call",

@@ -59,3 +59,29 @@ def test_sharded_path_on_one_rank_prints_one_line():
                WORLD_SIZE="1", LOCAL_RANK="0")
     d = run_bench("--no-cpu-baseline", env=env)
     assert d["n_gpus"] == 1 and d["value"] > 0 and sum(d["config"]["calls"]) == 5
+
+
+def test_two_ranks_on_one_card_take_the_onehop_path():
+    """bench.py as the driver launches it for N = 2 (one process per rank, RANK / WORLD_SIZE from the
+    environment), both ranks on the ONE card of this box with gloo as the host channel: the one-hop probe
+    succeeds, the shards exchange their moments in the sampling launch's tail, rank 0 prints the one line,
+    and the probability is what one process gets for the whole mixture (N = 2 x 20000)."""
+    import os
+    port = str(29600 + os.getpid() % 300)
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE="2",
+                   LOCAL_RANK=str(rank), POCS_FORCE_DEVICE="0", POCS_DIST_BACKEND="gloo", POCS_SKIP_SINGLE="1",
+                   POCS_NO_BOARD_PROBE="1")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                                       "--samples", "20000", "--no-cpu-baseline"], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, cwd=str(ROOT), env=env))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    lines = outs[0][0].splitlines()
+    assert len(lines) == 1 and outs[1][0].strip() == "", (outs[0][0], outs[1][0])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "tail" in d["config"]["exchange"] and d["config"]["engines_in_flight"] == 1, d["config"]
+    assert d["config"]["total_samples_per_run"] == 40000
+    one = run_bench("--no-cpu-baseline", "--samples", "40000", "--steps", "4")       # later flags win: N = 40000, 4 steps
+    assert d["config"]["probability"] == one["config"]["probability"]
