@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <chrono>
 
 #include "../../include/pocs.h"
 #include "pocs_kernels.h"
@@ -768,10 +769,16 @@ std::string config_key(const pocs_ctx* c, long long first, long long count, cons
 
 int run_gmm_full(pocs_ctx* c, double* probability) {
   if (!probability) return fail(c, POCS_E_ARG, "null output");
+  static const bool call_times = getenv("POCS_CALL_TIMES") != nullptr;     // tuning: host-side phases of a call on stderr
+  const auto t_in = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) { if (call_times) fprintf(stderr, "[call] %s +%.1f us\n", what,
+      std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count()); };
   if (int r = gmm_prepare(c)) return r;
   long long first, count;
   if (int r = gmm_shard(c, &first, &count)) return r;
+  lap("prepared");
   if (int r = gmm_upload_run(c)) return r;
+  lap("upload enqueued");
   const bool prof = c->opt_profile != 0;
   if (int r = prof_begin(c, gmm_hot_launches(c))) return r;
   if (c->opt_graph && !prof) {
@@ -793,8 +800,11 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
   } else {
     if (int r = enqueue_gmm_all(c, first, count, prof)) return r;
   }
+  lap("launched");
   prefetch_next_batch(c);          // host chains of the next batch, while the GPU works on this one
+  lap("next batch prepared");
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  lap("synchronised");
   if (int r = prof_collect(c, gmm_hot_launches(c))) return r;
   {
     unsigned gave_up = 0;
@@ -807,6 +817,7 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
 #if defined(POCS_STEP_STAMPS)
   step_stamps_report(c, count);
 #endif
+  lap("combined");
   return POCS_OK;
 }
 
