@@ -195,7 +195,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="independent runs (steps) advanced in lockstep per call (pocs_set_batch); "
                          "default 64 for the GMM path (the per-launch tail -- reduce, mixture advance, launch gap, "
-                         "~15 us -- is paid once per waypoint for the whole batch), 8 for MC (8 x 28 MB of particle "
+                         "~12 us -- is paid once per waypoint for the whole batch), 8 for MC (8 x 28 MB of particle "
                          "state stay in the 256 MB Infinity Cache between waypoint launches, 16 x do not)")
     ap.add_argument("--samples", type=int, default=0, help="override samples per GPU (experiments only)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],

@@ -686,14 +686,14 @@ int enqueue_ticket_reset(pocs_ctx* c) {
 }
 
 // k_gmm_run (the whole run in one queue-driven launch) or one k_gmm_step per waypoint?  Same tasks, same
-// arithmetic, bitwise the same results; which is faster is a matter of latency.  Measured on MI355X
-// (10^6 samples, K = 3): 64 runs per call 1.29 x 10^11 evals/s either way; 20 runs 1.00 (k_gmm_run) vs
-// 1.12; 8 runs 0.63 vs 0.95.  While the chip streams samples at 3 TB/s a memory round trip inside the
-// launch costs ~3 us instead of ~1, and closing a run's waypoint takes a dozen of them in a row
-// (ticket, acquire, the run's partial rows, the mixture's inputs, its stores, `ready`, and the same
-// again on the side that waits for it) -- with fewer than ~50 runs in flight that chain, not the
-// sampling, sets the pace.  The per-waypoint form pays them on an idle chip.  Hence: k_gmm_step by
-// default, k_gmm_run behind POCS_OPT_PERSISTENT.
+// arithmetic, bitwise the same results; which is faster is a matter of latency.  Measured on MI355X at the
+// end of round 2 (10^6 samples, K = 3, same box): 64 runs per call 1.40 (k_gmm_run) vs 1.46 x 10^11
+// evals/s; 20 runs 1.06 vs 1.25; 8 runs 0.70 vs 1.05; 1 run 0.17 vs 0.31.  While the chip streams samples
+// at 3+ TB/s a memory round trip inside the launch costs ~3 us instead of ~1, and closing a run's waypoint
+// takes a dozen of them in a row (ticket, acquire, the run's partial rows, the mixture's inputs, its
+// stores, `ready`, and the same again on the side that waits for it) -- with fewer than ~50 runs in flight
+// that chain, not the sampling, sets the pace.  The per-waypoint form pays them on an idle chip.  Hence:
+// k_gmm_step by default, k_gmm_run behind POCS_OPT_PERSISTENT.
 bool use_persistent(const pocs_ctx* c) { return c->opt_persistent != 0 && !c->ext_moments; }
 // How many launches of the hot kernel one whole-run call makes (what POCS_OPT_PROFILE brackets).
 size_t gmm_hot_launches(const pocs_ctx* c) { return use_persistent(c) ? 1 : (size_t)c->W; }
