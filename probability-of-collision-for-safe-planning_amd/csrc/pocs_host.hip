@@ -619,6 +619,17 @@ static void step_stamps_report(pocs_ctx* c, long long count) {
     for (auto& kv : by_cu) fprintf(stderr, " %d.%d: %.1f (%d)", kv.first / 16, kv.first % 16, kv.second.first / kv.second.second, kv.second.second);
     fprintf(stderr, "\n");
   }
+  {   // the advance in the closing blocks: staging, the K components (lanes of wave 0), the wait for the counts wave, publishing
+    double st = 0, comp = 0, wait = 0, fin = 0; int n = 0;
+    for (int w = 0; w + 1 < W; ++w)
+      for (int b = 0; b < R * S; ++b) {
+        const unsigned long long* q = &h[((size_t)w * R * S + b) * 32];
+        if (q[5] == 0 || q[26] == 0) continue;                 // not the closer of its run
+        st += (q[26] - q[4]) * 0.01; comp += (q[27] - q[26]) * 0.01; wait += (q[28] - q[27]) * 0.01; fin += (q[5] - q[28]) * 0.01; ++n;
+      }
+    if (n) fprintf(stderr, "[step stamps]   advance in %d closers (us): staging %.2f | components (wave 0) %.2f | -> counts wave done %.2f | normalise + publish %.2f\n",
+                   n, st / n, comp / n, wait / n, fin / n);
+  }
   fprintf(stderr, "[step stamps] R=%d S=%d per waypoint (us): start skew %.2f | head (first body start) %.2f | body mean %.2f | last body end - mean %.2f | "
           "-> all tickets %.2f | close_sums %.2f | advance %.2f | first start -> last stamp %.2f\n",
           R, S, skew / W, head / W, body / W, spread / W, ticket / W, close / W, adv / W, total / W);

@@ -318,11 +318,21 @@ __device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, 
 // The whole advance to waypoint w by a block of >= 128 threads (every thread calls it).
 __device__ __forceinline__ void advance_block(const pocs_gmm_launch& a, int K, int w, int r, double* adv, double* spec,
                                               bool mom_in_lds, int tid, int nthreads) {
+#if defined(POCS_STEP_STAMPS)      // k_gmm_step's closer only (w >= 1 there): where the advance spends its time
+  unsigned long long* const dbg_ = (mom_in_lds && gridDim.y > 1 + 0 * K) || mom_in_lds
+      ? a.dbg + (((size_t)(w - 1) * a.nruns + r) * a.slices + blockIdx.x) * 32 : nullptr;
+#define POCS_ADV_STAMP(i) do { if (dbg_ && tid == 0) dbg_[i] = wall_clock64(); } while (0)
+#else
+#define POCS_ADV_STAMP(i) do { } while (0)
+#endif
   advance_stage(a, K, w, r, adv, mom_in_lds, tid, nthreads);
   __syncthreads();
+  POCS_ADV_STAMP(26);
   if (tid < 64) advance_components(a, K, w, r, tid, adv);
   else if (tid == 64 && w > 0) speculate_counts(a, K, w, r, adv, spec);
+  POCS_ADV_STAMP(27);
   __syncthreads();
+  POCS_ADV_STAMP(28);
   if (tid < 64) advance_finish(a, K, w, r, tid, adv, w > 0 ? spec : nullptr);
 }
 // ... and by ONE wave (all 64 lanes call it), the moments of w-1 already in l_mom.
