@@ -407,7 +407,7 @@ def main():
                 rec["bytes_per_launch"] / rec["evals_per_launch"], rec["evals_per_launch"], rec["source"].split(":")[0], units)
     copy_gbps = ctx.copy_bandwidth(1 << 30)       # measured streaming-copy ceiling of this GPU, same process
     fill_gbps = ctx.fill_bandwidth(1 << 30)       # ... and the write-only one (the GMM kernels read nothing)
-    roofline = {"bound": "hbm", "limiter": ("FP64 VALU issue under the board's power cap, not bandwidth: ~190 vector instructions per evaluation "
+    roofline = {"bound": "hbm", "limiter": ("FP64 VALU issue under the board's power cap, not bandwidth: ~180 vector instructions per evaluation "
                                            "(profiles/r02_*_pmc.txt) keep the SIMDs issuing ~100 % of the time, and the kernel draws the "
                                            "1.4 kW cap at a shader clock of ~2.0 of 2.4 GHz (`board`, sampled live); the HBM fraction below is what "
                                            "that arithmetic reaches" if path == "gmm" else "HBM streaming (MC particle state read and written per waypoint)"),
