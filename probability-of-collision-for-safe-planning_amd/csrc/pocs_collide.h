@@ -91,3 +91,25 @@ POCS_HD bool pocs_pose_collides(double x, double y, double th, const pocs_footpr
   for (int m = 0; m < M; ++m) hit = hit | pocs_box_hit(px, py, sn, cs, fp->hx, fp->hy, obs + m * POCS_OBS_STRIDE);
   return hit;
 }
+
+// The footprint's largest half-extent along world x over all headings in [lo, hi] (along world y: the
+// same function of [lo - pi/2, hi - pi/2]): an upper bound, never more than the bounding radius.
+//   f(t) = rx |cos t| + ry |sin t| is concave between the multiples of pi/2 and peaks with the bounding
+//   radius at t = +-atan(ry / rx) + k pi: with no peak inside the range the maximum sits at an end.
+// k_gmm_step's culling uses it to give the records it keeps a broad phase that fits the task's headings
+// (gmm_cull); tests/test_product_host_vs_oracle.py scans f densely against it.
+POCS_HD double pocs_footprint_extent(double rx, double ry, double lo, double hi) {
+  const double rr = sqrt(rx * rx + ry * ry), PI = 3.14159265358979323846;
+  if (!(hi - lo < PI)) return rr;
+  const double phi = atan2(ry, rx);
+  for (int sgn = -1; sgn <= 1; sgn += 2) {
+    const double s = sgn * phi;
+    if (ceil((lo - s) / PI) <= floor((hi - s) / PI)) return rr;         // a peak inside the range
+  }
+  double sn, cs;
+  pocs_sincos(lo, &sn, &cs);
+  const double fa = fma(rx, fabs(cs), ry * fabs(sn));
+  pocs_sincos(hi, &sn, &cs);
+  const double fb = fma(rx, fabs(cs), ry * fabs(sn));
+  return fmin(rr, fmax(fa, fb) * (1.0 + 1e-9) + 1e-12);
+}

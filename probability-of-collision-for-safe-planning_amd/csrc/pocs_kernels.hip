@@ -474,24 +474,7 @@ __device__ __forceinline__ void gmm_stage_static(const pocs_gmm_launch& a, gmm_s
 // along world y over that range (two convex sets that touch overlap in every projection).  Where the
 // robot's heading is known to a fraction of a radian -- most of a plan -- far fewer poses reach the
 // narrow phase, and none that could touch is lost: the flags do not change.
-//   f(t) = rx |cos t| + ry |sin t| (world-x half extent; world-y: f(t - pi/2)) is concave between the
-//   multiples of pi/2 and peaks with the bounding radius at t = +-atan(ry / rx) + k pi.
-__device__ __forceinline__ double gmm_footprint_extent(const double rx, const double ry, const double lo, const double hi) {
-  const double rr = sqrt(rx * rx + ry * ry), PI = 3.14159265358979323846;
-  if (!(hi - lo < PI)) return rr;
-  const double phi = atan2(ry, rx);
-  for (int sgn = -1; sgn <= 1; sgn += 2) {
-    const double s = sgn * phi;
-    if (ceil((lo - s) / PI) <= floor((hi - s) / PI)) return rr;         // a peak inside the range
-  }
-  double sn, cs;
-  pocs_sincos(lo, &sn, &cs);
-  const double fa = fma(rx, fabs(cs), ry * fabs(sn));
-  pocs_sincos(hi, &sn, &cs);
-  const double fb = fma(rx, fabs(cs), ry * fabs(sn));
-  return fmin(rr, fmax(fa, fb) * (1.0 + 1e-9) + 1e-12);
-}
-
+//   (pocs_footprint_extent, pocs_collide.h: host + device, checked on the CPU against a dense scan)
 template <int K, int TB, int NB>
 __device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, TB, NB>& sm, const int buf, const int lane) {
   const pocs_footprint fp = a.fp;
@@ -509,8 +492,8 @@ __device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, T
   xlo -= pad; xhi += pad; ylo -= pad; yhi += pad;
   tlo -= 1e-9 * (1.0 + fabs(tlo)); thi += 1e-9 * (1.0 + fabs(thi));
   const double HALF_PI = 1.57079632679489661923;
-  const double ext_x = gmm_footprint_extent(fp.hx, fp.hy, tlo, thi);
-  const double ext_y = gmm_footprint_extent(fp.hx, fp.hy, tlo - HALF_PI, thi - HALF_PI);
+  const double ext_x = pocs_footprint_extent(fp.hx, fp.hy, tlo, thi);
+  const double ext_y = pocs_footprint_extent(fp.hx, fp.hy, tlo - HALF_PI, thi - HALF_PI);
   bool keep = false;
   double bx = 0.0, by = 0.0;
   if (lane < M) {

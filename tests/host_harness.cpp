@@ -49,6 +49,7 @@ void hh_ekf_update(double* mu, double* S, const double* z, int L, const double* 
   pocs_ekf_update(mu, S, z, &sen);
 }
 int hh_chol(const double* S, double* L) { return pocs_chol3_lower(S, L); }
+double hh_footprint_extent(double rx, double ry, double lo, double hi) { return pocs_footprint_extent(rx, ry, lo, hi); }
 int hh_collides(double x, double y, double th, const double* fp4, const double* boxes, int M) {
   pocs_footprint fp = {fp4[0], fp4[1], fp4[2], fp4[3]};
   double obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];

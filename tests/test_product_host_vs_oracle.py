@@ -296,3 +296,26 @@ def test_component_counts_are_multinomial(orc, plan, env):
     state[:, 12] = 0.0
     state[:, 13] = 0.0
     assert list(orc.component_counts(4, state, 5, 0, 77)) == [77.0] * 4
+
+
+def test_footprint_extent_bounds_every_heading_of_the_range(hh):
+    """pocs_footprint_extent (the broad phase k_gmm_step's culling gives the records it keeps): never
+    below the footprint's half-extent at ANY heading of the range (dense scan), never above the bounding
+    radius, and tight -- equal to the scan's maximum to 1e-6 -- so that it actually prunes."""
+    hh.hh_footprint_extent.restype = C.c_double
+    hh.hh_footprint_extent.argtypes = [C.c_double] * 4
+    rng = np.random.default_rng(5)
+    for case in range(400):
+        rx, ry = rng.uniform(0.05, 0.6, 2)
+        if case % 5 == 0:
+            ry = rx
+        centre = rng.uniform(-12.0, 12.0)
+        width = rng.choice([1e-6, 0.01, 0.1, 0.3, 0.8, 1.4, 1.6, 3.0, 3.2, 7.0])
+        lo, hi = centre - width / 2, centre + width / 2
+        got = hh.hh_footprint_extent(rx, ry, lo, hi)
+        t = np.linspace(lo, hi, 20001)
+        scan = (rx * np.abs(np.cos(t)) + ry * np.abs(np.sin(t))).max()
+        rr = float(np.hypot(rx, ry))
+        assert scan <= got <= rr * (1 + 1e-15), (rx, ry, lo, hi, got, scan)
+        # tight: the scan's maximum, or the bounding radius where a peak of f lies inside the range
+        assert got - scan < 1e-6 or (got == rr and rr - scan < 1e-6 + 1e-3 * width ** 2), (rx, ry, lo, hi, got, scan)
