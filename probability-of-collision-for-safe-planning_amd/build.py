@@ -31,13 +31,24 @@ def build_library(force=False, verbose=False):
     """Compile csrc/*.hip into libpocs.so next to this file; returns its path."""
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + [str(CSRC / s) for s in SOURCES] + ["-o", str(LIB)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if verbose or r.returncode:
-        print(" ".join(cmd))
-        print(r.stdout, r.stderr)
-    if r.returncode:
-        raise RuntimeError("hipcc failed building libpocs.so")
+    # One builder at a time (the ranks of a multi-GPU job all import the package at once), and the library
+    # appears atomically: compile to a private name, then rename.
+    import fcntl
+    with open(PKG / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not stale():                # another process built it while this one waited
+            return LIB
+        tmp = PKG / (".libpocs.%d.so" % os.getpid())
+        cmd = [hipcc()] + FLAGS + [str(CSRC / s) for s in SOURCES] + ["-o", str(tmp)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose or r.returncode:
+            print(" ".join(cmd))
+            print(r.stdout, r.stderr)
+        if r.returncode:
+            if tmp.exists():
+                tmp.unlink()
+            raise RuntimeError("hipcc failed building libpocs.so")
+        os.replace(tmp, LIB)
     return LIB
 
 
