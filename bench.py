@@ -173,6 +173,11 @@ def probe_onehop(par, pocs_amd, torch, dist, rank, world, local):
         print("one-hop probe: %s" % exc, file=sys.stderr)
         ok = 0
     finally:
+        if dist is not None:
+            try:
+                dist.barrier()                         # nobody unmaps a buffer another rank may still be writing to
+            except Exception:                          # noqa: BLE001
+                pass
         if ctx is not None:
             try:
                 ctx.close()
@@ -469,6 +474,8 @@ def main():
         os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+    if dist is not None:
+        fence()                                        # every rank is done with every rank's exchange buffer
     for c, _ in made:
         c.close()
     if dist is not None:
