@@ -761,30 +761,44 @@ __device__ __forceinline__ double gmm_row_total(const double (*s_red)[NC], const
 }
 
 // The closer of (r, w) -- the block (k_gmm_step) or wave (k_gmm_run) that drew the run's last ticket,
-// behind its acquire -- adds the a.slices partial rows of the run IN SLICE ORDER, column by column:
-// `nthreads` threads bring RB rows at a time to `stage` (L1-bypassing loads, all in flight at once),
-// then thread c adds them to column c.  `sync` = the barrier of those threads.  The collisions of a
-// component are what is left of its block of this shard's samples: nColl_k = n_k - nFree_k, with
-// [cum_{k-1}, cum_k) the component's global sample range (par[k][9], cum_{K-1} = n_total).
-// Result: tot[c], and moments[w][r][c] in global memory (it leaves the launch at the kernel boundary).
+// behind its acquire -- adds the a.slices partial rows of the run in a FIXED order that does not depend
+// on who adds them: sixteen interleaved partial sums per column, P_g = row g + row (g + 16) + row (g + 32)
+// + ... in that order, then P_0 + P_1 + ... + P_15 in that order.  (Up to 16 slices -- 32 runs per
+// launch and more -- that is plain slice order.)  Every (g, column) is one work item: its loads are
+// L1-bypassing and independent, so the `nthreads` threads have the whole table in flight at once --
+// ONE memory round trip instead of one per 32 rows, which is what a lone run's 256 slices used to
+// cost (7 us of a 31 us launch).  `stage`: >= 16 * NC doubles of LDS.  `sync` = the barrier of those
+// threads.  The collisions of a component are what is left of its block of this shard's samples:
+// nColl_k = n_k - nFree_k, with [cum_{k-1}, cum_k) the component's global sample range (par[k][9],
+// cum_{K-1} = n_total).  Result: tot[c], and moments[w][r][c] in global memory (it leaves the launch at
+// the kernel boundary).
 template <int K, int RB, typename Sync>
 __device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const int w, const int r, const double* s_par,
                                                double* stage, double* tot, const int tid, const int nthreads, Sync sync) {
-  constexpr int NC = K * POCS_NMOM;
+  constexpr int NC = K * POCS_NMOM, G = 16;
+  static_assert(RB >= G, "the staging rows hold the sixteen partial sums");
   const int S = a.slices;
-  for (int c = tid; c < NC; c += nthreads) tot[c] = 0.0;
-  for (int b0 = 0; b0 < S; b0 += RB) {
-    const int nrow = (S - b0 < RB) ? S - b0 : RB;
-    const double* src = a.partial + ((size_t)r * S + b0) * NC;
-    stage_batched<8>(stage, nrow * NC, tid, nthreads, [&](int i) -> double { return load_wt(&src[i]); });
-    sync();
-    for (int c = tid; c < NC; c += nthreads) {
-      double v = tot[c];
-      for (int q = 0; q < nrow; ++q) v += stage[q * NC + c];
-      tot[c] = v;
+  const double* src = a.partial + (size_t)r * S * NC;
+  for (int i = tid; i < G * NC; i += nthreads) {
+    const int g = i / NC, c = i - g * NC;
+    double v = 0.0;
+    int q = g;
+    for (; q + 3 * G < S; q += 4 * G) {              // four rows of the item in flight at a time, added in row order
+      const double v0 = load_wt(&src[(size_t)q * NC + c]), v1 = load_wt(&src[(size_t)(q + G) * NC + c]);
+      const double v2 = load_wt(&src[(size_t)(q + 2 * G) * NC + c]), v3 = load_wt(&src[(size_t)(q + 3 * G) * NC + c]);
+      v += v0; v += v1; v += v2; v += v3;
     }
-    sync();
+    for (; q < S; q += G) v += load_wt(&src[(size_t)q * NC + c]);
+    stage[i] = v;
   }
+  sync();
+  for (int c = tid; c < NC; c += nthreads) {
+    double v = stage[c];
+    const int ng = S < G ? S : G;
+    for (int g = 1; g < ng; ++g) v += stage[g * NC + c];
+    tot[c] = v;
+  }
+  sync();
   const double lo = (double)a.first, hi = (double)(a.first + a.count);
   for (int k = tid; k < K; k += nthreads) {
     const double c0 = (k == 0) ? 0.0 : s_par[(k - 1) * POCS_PARAM_STRIDE + 9];
