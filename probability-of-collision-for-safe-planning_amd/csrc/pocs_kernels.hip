@@ -10,20 +10,26 @@
 //                             A task (both kernels):
 //                             head  log/sector tables, obstacle table and this waypoint's sampler
 //                                   parameters -> LDS; exact culling of the obstacle table against
-//                                   the mixture's bounding box;
+//                                   the mixture's bounding box, the kept records' broad phase
+//                                   tightened to the task's range of headings;
 //                             body  GM_Model::sampleNPoints (GM_Model.h:83-116) + checkMatrixCollisions
 //                                   (:241-253) + the moment sums (:592-611), fused, one PAIR of
 //                                   samples per thread-iteration: a sample is born, tested and folded
 //                                   into its component's (n, sum x, sum x x^T) in registers; pose
-//                                   and flag are streamed out once (24 B + 2 B);
+//                                   and flag are streamed out once (24 B + 2 B).  A wave whose 128
+//                                   samples lie in one component block (nearly always) runs the
+//                                   iteration's scalar-component form in an inner loop of its own;
 //                             tail  DPP row sums -> LDS -> one write-through partial row per block ->
-//                                   the last block to arrive adds the rows in a fixed order and (one
-//                                   GPU) advances the mixture to the next waypoint: truncated
-//                                   mean/cov, weights (:597-629), per-component EKF predict/update
-//                                   (:766-771, :804-812), Cholesky.
+//                                   the last block to arrive adds the rows in a fixed order and
+//                                   advances the mixture to the next waypoint: truncated mean/cov,
+//                                   weights (:597-629), per-component EKF predict/update (:766-771,
+//                                   :804-812), Cholesky -- on one GPU right away, sharded after it has
+//                                   exchanged the run's moments with the other ranks (IPC slots, one
+//                                   hop over xGMI) in the same tail.
 //                             The waypoint loop never returns to the host.
 //   k_gmm_advance   T1 tail   the same mixture advance as its own launch (waypoint 0; after the
-//                             caller's all-reduce when the samples are sharded over GPUs).
+//                             caller's all-reduce when the shards exchange their moments that way).
+//   k_gmm_exchange  T1 tail   exchange + advance as their own launch (the step API's two-launch form).
 //   k_mc_init       P2+P3     initParticles (:287-297) + first checkParticleCollisions (:333-347)
 //   k_mc_step       P1+P3     moveParticles (:300-322) + checkParticleCollisions, one waypoint,
 //                             particles streamed through HBM (SoA): 24 B in, 24 B out, u32 RMW.
