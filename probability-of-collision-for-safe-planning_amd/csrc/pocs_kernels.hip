@@ -131,6 +131,14 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #ifndef POCS_WT_BITS
 #define POCS_WT_BITS "sc1"
 #endif
+// the same addressing for the per-waypoint kernel's non-temporal stream (the compiler, left to itself,
+// builds a 64-bit address per lane and store: four vector adds per iteration)
+__device__ __forceinline__ void store16_nt(const void* base_uniform, unsigned lane_bytes, v2d v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_bytes), "v"(v), "s"(base_uniform) : "memory");
+}
+__device__ __forceinline__ void store4_nt(const void* base_uniform, unsigned lane_bytes, int v) {
+  asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(lane_bytes), "v"(v), "s"(base_uniform) : "memory");
+}
 __device__ __forceinline__ void store16_wt(const void* base_uniform, unsigned lane_bytes, v2d v) {
   asm volatile("global_store_dwordx4 %0, %1, %2 " POCS_WT_BITS "\n\ts_nop 1" ::"v"(lane_bytes), "v"(v), "s"(base_uniform) : "memory");
 }
@@ -705,10 +713,10 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
         store16_wt(tr + ub, 16u * (unsigned)tid, (v2d){ts[0], ts[1]});
         store4_wt(fr + ub, 4u * (unsigned)tid, fl);
       } else {                                     // a launch per waypoint: non-temporal, past the caches
-        __builtin_nontemporal_store((v2d){xs[0], xs[1]}, reinterpret_cast<v2d*>(xr + ub) + tid);
-        __builtin_nontemporal_store((v2d){ys[0], ys[1]}, reinterpret_cast<v2d*>(yr + ub) + tid);
-        __builtin_nontemporal_store((v2d){ts[0], ts[1]}, reinterpret_cast<v2d*>(tr + ub) + tid);
-        __builtin_nontemporal_store(fl, reinterpret_cast<int*>(fr + ub) + tid);
+        store16_nt(xr + ub, 16u * (unsigned)tid, (v2d){xs[0], xs[1]});
+        store16_nt(yr + ub, 16u * (unsigned)tid, (v2d){ys[0], ys[1]});
+        store16_nt(tr + ub, 16u * (unsigned)tid, (v2d){ts[0], ts[1]});
+        store4_nt(fr + ub, 4u * (unsigned)tid, fl);
       }
     }
   };
