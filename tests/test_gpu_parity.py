@@ -554,6 +554,38 @@ def test_error_behaviour(pocs, plan, env):
         c.close()
 
 
+def test_step_api_refuses_calls_out_of_sequence(pocs, plan, env):
+    """The per-waypoint API of the sharded path: every call out of sequence is an error (POCS_E_ORDER),
+    never a launch on half-built state -- the in-tail exchange included, which needs its buffers."""
+    with pocs.Context(0) as c:
+        c.configure(plan, env, K=3, N=2000, seed=3)
+        for call in (lambda: c.gmm_sample_local(0), lambda: c.gmm_sample_exchange_local(0), lambda: c.gmm_end()):
+            with pytest.raises(pocs.PocsError) as e:
+                call()                                            # before gmm_begin
+            assert e.value.code == -2
+        c.gmm_begin()
+        with pytest.raises(pocs.PocsError) as e:
+            c.gmm_sample_exchange_local(0)                        # no exchange buffers connected
+        assert e.value.code == -2 and "pocs_xchg_connect" in str(e.value)
+        with pytest.raises(pocs.PocsError) as e:
+            c.gmm_sample_local(0)                                 # the mixture of waypoint 0 does not exist yet
+        assert e.value.code == -2
+        c.gmm_advance_local(0)
+        with pytest.raises(pocs.PocsError) as e:
+            c.gmm_sample_local(1)                                 # waypoint 0 first
+        assert e.value.code == -2
+        c.xchg_connect([c.xchg_create(1, 0)])                     # a world of one: the exchange is with itself
+        c.gmm_sample_exchange_local(0)
+        with pytest.raises(pocs.PocsError) as e:
+            c.gmm_end()                                           # 55 waypoints to go
+        assert e.value.code == -2
+        for w in range(1, 56):
+            c.gmm_sample_exchange_local(w)
+        p = c.gmm_end()
+        c.set_seed(3)
+        assert p == c.run_gmm_estimation()                        # and it is the whole-run call's result
+
+
 def test_graphs_survive_buffer_growth(pocs, orc, plan, env):
     """A captured launch graph bakes device pointers in.  MC at batch 1 captures graph_mc; a GMM call
     with run-ahead 16 then grows the shared header / chain buffers (freed and reallocated); the next
