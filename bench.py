@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="independent runs (steps) advanced in lockstep per call (pocs_set_batch); "
                          "default 64 for the GMM path (the per-launch tail -- reduce, mixture advance, launch gap, "
-                         "~12 us -- is paid once per waypoint for the whole batch), 8 for MC (8 x 28 MB of particle "
+                         "~12 us -- is paid once per waypoint for the whole batch), 8 x 10^6 / particles for MC (8 x 28 MB of particle "
                          "state stay in the 256 MB Infinity Cache between waypoint launches, 16 x do not)")
     ap.add_argument("--samples", type=int, default=0, help="override samples per GPU (experiments only)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -253,7 +253,9 @@ def main():
 
     # K steps are issued as `ncalls` calls of nearly equal batch: `n_hi` calls of b_hi = b_lo + 1
     # runs and the rest of b_lo runs.
-    maxb = args.batch if args.batch > 0 else (64 if path == "gmm" else 8)
+    # MC: as many roll-outs per launch as keep 8 x 10^6 particles' state (28 B each) in flight -- what stays in
+    # the 256 MB Infinity Cache between two waypoint launches: 8 at 10^6 particles, 64 at 10^5 (cfg5: 0.41 -> 0.75)
+    maxb = args.batch if args.batch > 0 else (64 if path == "gmm" else max(1, min(64, int(8_000_000 // max(n_local, 1)))))
     ncalls = (args.steps + maxb - 1) // maxb
     # How the shards of the GMM path exchange their moments (POCS_ONEHOP): "2" = the library's one-hop
     # exchange in the sampling launch's tail (one launch per waypoint, ONE engine, as on one GPU; the
