@@ -72,7 +72,9 @@ int pocs_send_command(pocs_ctx* ctx, const char* line, char* out, size_t cap);
 #define POCS_OPT_MC_FUSED 2        /* 0 (default): one launch per waypoint, particles streamed through HBM (56 B/eval); 1: whole roll-out in registers */
 #define POCS_OPT_USE_GRAPH 3       /* 1 (default): the per-run launch sequence is replayed from a hipGraph */
 #define POCS_OPT_PROFILE 4         /* 1: bracket the hot kernel with hipEvents (see pocs_get_kernel_time) */
-#define POCS_OPT_RUN_AHEAD 5       /* R > 1 (default 1 = off): with one run per call (batch 1), a run* call evaluates the NEXT R
+#define POCS_OPT_RUN_AHEAD 5       /* R > 1, or 0 = R sized per call from the sample / particle count (8..64: the reference's 200 runs
+                                      of 10^4 samples go 64 at a time, a 10^6-sample estimation 16 at a time); default 1 = off.
+                                      With one run per call (batch 1), a run* call evaluates the NEXT R
                                       runs of the context in one launch and the following R-1 calls are served from it -- the
                                       reference driver's one-command-per-run loop (MCSimulation.py:238-256) at batch throughput.
                                       Same runs, same seeds, same results and getters as one launch per run; any setter ends the

@@ -29,9 +29,10 @@ class MCModule : public ModuleBase {
       RegisterCommand(n, boost::bind(&MCModule::Forward, this, std::string(n), _1, _2), "see include/pocs.h");
     HandOverScene(penv);
     // The reference driver issues one run* command per run, 200 in a row (MCSimulation.py:238-256):
-    // evaluate them 16 at a time behind that interface (POCS_RUN_AHEAD overrides; 1 = off).
+    // evaluate them several at a time behind that interface -- 0 = as many as the sample count calls
+    // for, 8..64 (POCS_RUN_AHEAD overrides; 1 = off).
     const char* ra = getenv("POCS_RUN_AHEAD");
-    impl_.SendCommand(std::string("setRunAhead ") + (ra ? ra : "16"));
+    impl_.SendCommand(std::string("setRunAhead ") + (ra ? ra : "0"));
   }
   bool Forward(const std::string& name, std::ostream& sout, std::istream& sinput) {
     std::stringstream line;

@@ -1175,8 +1175,8 @@ int pocs_set_option(pocs_ctx* c, int option, long long value) {
     case POCS_OPT_PROFILE: c->opt_profile = value ? 1 : 0; break;
     case POCS_OPT_PERSISTENT: c->opt_persistent = value ? 1 : 0; break;
     case POCS_OPT_RUN_AHEAD:
-      if (value < 1 || value > 256) return fail(c, POCS_E_ARG, "run-ahead %lld outside 1..256", value);
-      c->run_ahead = (int)value;
+      if (value < 0 || value > 256) return fail(c, POCS_E_ARG, "run-ahead %lld outside 0..256", value);
+      c->run_ahead = (int)value;                     // 0 = sized per call (ra_depth)
       break;
     default: return fail(c, POCS_E_ARG, "unknown option %d", option);
   }
@@ -1233,8 +1233,18 @@ int pocs_gmm_bind_moments(pocs_ctx* c, void* dptr, long long len) {
 static bool ra_can_serve(const pocs_ctx* c, int kind) {
   return c->ra_have > 0 && c->ra_kind == kind && c->batch == 1 && c->view + 1 < c->ra_have;
 }
-static bool ra_wanted(const pocs_ctx* c) {
-  return c->run_ahead > 1 && c->batch == 1 && c->shard_first < 0 && !c->opt_profile && !c->ext_moments && !c->gmm_open;
+// Runs evaluated per launch when run-ahead is on.  0 (automatic): enough runs to keep the chip busy for the
+// launch's fixed cost to fade -- 1.6 x 10^7 mixture samples or 8 x 10^6 particles (what stays in the
+// Infinity Cache between two waypoint launches) per launch, at least 8, at most 64: the reference's
+// own 200 runs of 10^4 samples go 64 at a time, a 10^6-sample estimation 16 at a time.
+static int ra_depth(const pocs_ctx* c, int kind) {
+  if (c->run_ahead != 0) return c->run_ahead;
+  const long long n = kind == 1 ? c->num_gmm : c->num_particles;
+  const long long want = (kind == 1 ? 16000000LL : 8000000LL) / (n > 0 ? n : 1);
+  return (int)(want < 8 ? 8 : want > 64 ? 64 : want);
+}
+static bool ra_wanted(const pocs_ctx* c, int kind) {
+  return ra_depth(c, kind) > 1 && c->batch == 1 && c->shard_first < 0 && !c->opt_profile && !c->ext_moments && !c->gmm_open;
 }
 static void mc_fill_probs(pocs_ctx* c) {
   // getCollisionProportion, MCSimulator.h:324-330 (of the particles this context evaluated)
@@ -1254,11 +1264,12 @@ int pocs_run_gmm_estimation(pocs_ctx* c, double* probability) {
   }
   ra_drop(c);
   c->ra_internal = false;
-  if (!ra_wanted(c)) return run_gmm_full(c, probability);
-  c->batch = c->run_ahead;
+  if (!ra_wanted(c, 1)) return run_gmm_full(c, probability);
+  const int depth = ra_depth(c, 1);
+  c->batch = depth;
   const int rc = run_gmm_full(c, probability);
   c->batch = 1;
-  if (rc == POCS_OK) { c->ra_have = c->run_ahead; c->ra_kind = 1; c->ra_internal = true; }
+  if (rc == POCS_OK) { c->ra_have = depth; c->ra_kind = 1; c->ra_internal = true; }
   return rc;
 }
 
@@ -1273,13 +1284,14 @@ int pocs_run_simulation(pocs_ctx* c, double* probability) {
   }
   ra_drop(c);
   c->ra_internal = false;
-  const bool ra = ra_wanted(c);
-  if (ra) c->batch = c->run_ahead;
+  const bool ra = ra_wanted(c, 2);
+  const int depth = ra_depth(c, 2);
+  if (ra) c->batch = depth;
   const int rc = run_mc_local(c);
   c->batch = ra ? 1 : c->batch;
   if (rc) return rc;
   mc_fill_probs(c);
-  if (ra) { c->ra_have = c->run_ahead; c->ra_kind = 2; c->ra_internal = true; }
+  if (ra) { c->ra_have = depth; c->ra_kind = 2; c->ra_internal = true; }
   *probability = c->batch_probs[0];
   return POCS_OK;
 }

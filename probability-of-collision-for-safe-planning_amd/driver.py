@@ -107,7 +107,7 @@ def run_experiment(simoption, num_runs=200, num_particles=10000, num_gaussians=3
     with Context(device) as mod, open(journal, "w") as f2:
         push_configuration(mod, plan, env, params, num_particles, simoption, num_gaussians)
         mod.SendCommand("setSeed " + str(int(seed)))
-        if int(run_ahead) > 1:
+        if int(run_ahead) != 1:                      # 0 = sized by the library from the sample count
             mod.SendCommand("setRunAhead " + str(int(run_ahead)))
         command = "runSimulation" if simoption == "MC" else "runGMMEstimation"
         batch = max(1, int(batch))

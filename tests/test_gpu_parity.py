@@ -674,7 +674,7 @@ def test_run_ahead_serves_the_same_runs(pocs, plan, env, mc):
         with pocs.Context(0) as c:
             c.configure(plan, env, K=K, N=N, seed=41)
             c.set_num_particles(N)
-            if run_ahead > 1:
+            if run_ahead != 1:
                 c.send_command("setRunAhead %d" % run_ahead)
             run = c.run_simulation if mc else c.run_gmm_estimation
             for i in range(11):
@@ -687,9 +687,11 @@ def test_run_ahead_serves_the_same_runs(pocs, plan, env, mc):
             out.append((run(), _snapshot(c, K, N, mc)))
         return out
 
-    one, ahead = sequence(1), sequence(4)
-    assert len(one) == len(ahead) == 16
+    one, ahead, auto = sequence(1), sequence(4), sequence(0)      # 0: the depth sized from N (64 here)
+    assert len(one) == len(ahead) == len(auto) == 16
     tol = 0.0 if mc else 2.0 / N          # GMM moments are summed over another block layout when batched
+    for i, ((p1, _), (p3, s3)) in enumerate(zip(one, auto)):
+        assert abs(p1 - p3) <= tol and s3["bp"] == [p3], i
     for i, ((p1, s1), (p2, s2)) in enumerate(zip(one, ahead)):
         assert abs(p1 - p2) <= tol, i
         assert s2["bp"] == [p2], i                           # the caller asked for one run at a time
