@@ -615,6 +615,13 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
     uint32_t spare[2];
 #if defined(POCS_ABLATE_RNG)          // timing-only builds (tools/ablate.sh): outputs are wrong
     for (int h = 0; h < 2; ++h) { zz[h][0] = (double)(lp & 7) * 0.1; zz[h][1] = (double)(lp & 3) * 0.1; zz[h][2] = 0.05; spare[h] = (uint32_t)lp * 2654435761u; }
+#elif defined(POCS_ABLATE_PHILOX)      // Box-Muller kept, its words from a three-instruction hash: what Philox costs in situ
+    { const uint32_t q = (uint32_t)(pair0 + lp) * 2654435761u ^ (uint32_t)seed ^ ((uint32_t)w << 20);
+      const uint32_t a0 = q * 0x9E3779B1u, a1 = (q ^ 0x85EBCA6Bu) * 0xC2B2AE35u, a2 = (q + 0x27D4EB2Fu) * 0x165667B1u;
+      pocs_normal_pair_w2(a0, a1, s_tab, &zz[0][0], &zz[0][1]);
+      pocs_normal_pair_w2(a2, a0 ^ a1, s_tab, &zz[0][2], &zz[1][0]);
+      pocs_normal_pair_w2(a1 ^ a2, a0 + a2, s_tab, &zz[1][1], &zz[1][2]);
+      spare[0] = a0; spare[1] = a1; }
 #elif defined(POCS_ABLATE_BOXMULLER)
     { const pocs_u32x4 A = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 0u), B = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 1u);
       zz[0][0] = (double)A.x * 0x1p-32; zz[0][1] = (double)A.y * 0x1p-32; zz[0][2] = (double)A.z * 0x1p-32; spare[0] = B.z;
