@@ -288,8 +288,6 @@ def main():
             c.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
         if os.environ.get("POCS_NO_GRAPH") == "1":       # diagnostic builds that synchronise inside the launch sequence
             c.set_option(pocs_amd.OPT_USE_GRAPH, 0)
-        if os.environ.get("POCS_PERSISTENT") == "1":     # A/B: the whole run as one queue-driven launch (k_gmm_run)
-            c.set_option(pocs_amd.OPT_PERSISTENT, 1)
         if sharded:     # one rank per GPU: launches on a torch stream, moments in a torch tensor
             return c, par.GpuEngine(c, W, K, N, rank=rank, world=world, per_rank=n_local, batch=b, stream=stream)
         c.set_batch(b)
@@ -393,10 +391,7 @@ def main():
     kern = "k_gmm_step" if path == "gmm" else ("k_mc_fused" if args.mc_fused else "k_mc_step")
     bpe = BYTES_PER_EVAL_GMM if path == "gmm" else BYTES_PER_EVAL_MC
     avg_ms = ms_tot / max(n_launch, 1)
-    persistent = path == "gmm" and not sharded and os.environ.get("POCS_PERSISTENT") == "1"
-    kern = "k_gmm_run" if persistent else kern
-    # evaluations one launch of the hot kernel processes: k_gmm_run covers all W waypoints of the batch
-    units = n_local * batch * (W if persistent else 1)
+    units = n_local * batch                         # evaluations one launch of the hot kernel processes
     achieved = (bpe * units) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE
     # correction applied) are taken offline and committed with their source in profiles/traffic.json

@@ -96,6 +96,8 @@ int pocs_set_option(pocs_ctx* ctx, int option, long long value);
  * batched the same way (pocs_mc_get_batch_counts: the shard's collided particles per run). */
 int pocs_set_batch(pocs_ctx* ctx, int runs);
 int pocs_get_batch_probabilities(pocs_ctx* ctx, double* out, int cap);
+int pocs_select_batch_run(pocs_ctx* ctx, int run);   /* the getters below (waypoint probabilities, moments, mixture state, host chain,
+                                                        samples / particles) expose run `run` of the last batch; a new launch selects run 0 */
 
 /* ---- sharding over GPUs (one process per GPU; the caller owns the collective) -----------
  * A context evaluates global sample / particle indices [first, first+count) of the N configured;
@@ -150,7 +152,9 @@ long long pocs_copy_gmm_samples(pocs_ctx* ctx, double* xyt_aos, int16_t* flags, 
 long long pocs_copy_particles(pocs_ctx* ctx, double* xyt_aos, uint32_t* hits, long long cap);   /* mcparticles / particlecollisions, MCSimulator.h:105,108 */
 int pocs_measure_copy_bandwidth(pocs_ctx* ctx, long long bytes, double* gbps);  /* read+write GB/s of a plain streaming copy on this GPU: the measured HBM ceiling */
 int pocs_measure_fill_bandwidth(pocs_ctx* ctx, long long bytes, double* gbps);  /* written GB/s of a plain streaming fill: the write-only ceiling (the GMM kernels read nothing) */
-int pocs_get_kernel_time(pocs_ctx* ctx, double* total_ms, long long* launches);  /* hot-kernel time of the last run with POCS_OPT_PROFILE=1 */
+int pocs_get_kernel_time(pocs_ctx* ctx, double* total_ms, long long* launches);  /* hot-kernel time of the last run with POCS_OPT_PROFILE=1 (of the launches on the context's stream) */
+int pocs_get_sequence_time(pocs_ctx* ctx, double* ms, int* concurrent);  /* POCS_OPT_PROFILE=1, whole-run GMM calls: first sampling launch -> end of the last one, and how many
+                                                                            sub-batches of the call were in flight side by side (their launches overlap: DESIGN.md section 5) */
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,11 @@ class Oracle:
         L.orc_log_unit32.restype = C.c_double
         L.orc_log_unit32.argtypes = [C.c_uint32]
 
+    def set_sum_order(self, order):
+        """1 (default): the build's summation tree (numerics v7; the HIP path agrees bit for bit);
+        0: plain sequential sums over the free set in sample order."""
+        self.lib.orc_set_sum_order(C.c_int(1 if order else 0))
+
     # ---- primitives -------------------------------------------------------------------
     def philox(self, ctr, key):
         c = (C.c_uint32 * 4)(*ctr)

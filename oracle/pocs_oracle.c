@@ -50,7 +50,7 @@
 #define ORC_STATE 16
 
 /* ------------------------------------------------------------------------------------------ */
-/* random streams (build spec "POCS numerics v6")                          */
+/* random streams (build spec "POCS numerics v7")                          */
 /* ------------------------------------------------------------------------------------------ */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
@@ -730,6 +730,92 @@ void orc_component_counts(int K, const double* state, uint64_t seed, int waypoin
   }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* The sums of truncateGMM (MCSimulator.h:592-611) over the free samples of each component.  The reference
+ * takes mean(free,1) and cov(free^T) with Armadillo (op_mean / op_cov -> BLAS), whose summation order is
+ * whatever the library's kernels do -- it has no canonical order.  The build fixes one (DESIGN.md section
+ * 4, "summation tree", numerics v7), a function of the shard's sample count only:
+ *   the shard's pairs of samples (2 lp, 2 lp + 1) in CHUNKS of 512 pairs; the chunks cut into
+ *   VS = the largest power of two <= min(256, chunks) VIRTUAL SLICES, slice j = chunks
+ *   [j chunks / VS, (j + 1) chunks / VS); pair lp = 512 c + 64 v + l sits in chunk c, WAVE v, LANE l;
+ *   lane chain  the free samples of one component that lane l of wave v meets in slice j, in chunk
+ *               order, sample 2 lp before 2 lp + 1: s += x ..., sxx = fma(x, x, sxx) ...
+ *   wave sum    the 64 lane chains: g_q = lanes 8q .. 8q+7 added in lane order, then
+ *               ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7))
+ *   row         of (slice, component): the eight wave sums in wave order
+ *   total       sixteen interleaved partial sums P_g = row g + row (g + 16) + ..., then P_0 + ... + P_15
+ * order 0 = the plain sequential sums over the free set in sample order (what this file did before v7;
+ * kept to show how far two orders lie apart: tests/test_oracle_sum_orders.py).                          */
+/* ------------------------------------------------------------------------------------------ */
+static int g_sum_order = 1;
+void orc_set_sum_order(int order) { g_sum_order = order ? 1 : 0; }
+int orc_get_sum_order(void) { return g_sum_order; }
+
+static void tree_moments(int K, long long count, const double* pts, const unsigned char* hit,
+                         const unsigned char* comp, double* moments) {
+  enum { TB = 512, LANES = 64, WAVES = TB / LANES, NS = 9 };
+  long long npairs = (count + 1) / 2;
+  long long chunks = (npairs + TB - 1) / TB;
+  if (chunks < 1) chunks = 1;
+  int sh = 0;
+  while ((2LL << sh) <= chunks && (2 << sh) <= 256) ++sh;
+  int VS = 1 << sh;
+  double* rows = (double*)calloc((size_t)VS * ORC_MAX_K * (NS + 1), sizeof(double));   /* [slice][k][n, 9 sums] */
+  static double chain[ORC_MAX_K][LANES][NS];
+  for (int j = 0; j < VS; ++j) {
+    long long cb = ((long long)j * chunks) >> sh, ce = ((long long)(j + 1) * chunks) >> sh;
+    for (int v = 0; v < WAVES; ++v) {
+      long long n_k[ORC_MAX_K];
+      for (int k = 0; k < K; ++k) { n_k[k] = 0; memset(chain[k], 0, sizeof chain[k]); }
+      for (long long c = cb; c < ce; ++c)
+        for (int l = 0; l < LANES; ++l) {
+          long long lp = c * TB + (long long)v * LANES + l;
+          for (int h = 0; h < 2; ++h) {
+            long long i = 2 * lp + h;
+            if (i >= count || hit[i]) continue;
+            const double* p = pts + 3 * i;
+            double* a = chain[comp[i]][l];
+            ++n_k[comp[i]];
+            a[0] += p[0]; a[1] += p[1]; a[2] += p[2];
+            a[3] = fma(p[0], p[0], a[3]); a[4] = fma(p[0], p[1], a[4]); a[5] = fma(p[0], p[2], a[5]);
+            a[6] = fma(p[1], p[1], a[6]); a[7] = fma(p[1], p[2], a[7]); a[8] = fma(p[2], p[2], a[8]);
+          }
+        }
+      for (int k = 0; k < K; ++k) {
+        double* row = rows + ((size_t)j * ORC_MAX_K + k) * (NS + 1);
+        double wn = (double)n_k[k];
+        row[0] = (v == 0) ? wn : row[0] + wn;
+        for (int s = 0; s < NS; ++s) {
+          double g[8];
+          for (int q = 0; q < 8; ++q) {
+            double t = chain[k][8 * q][s];
+            for (int l = 1; l < 8; ++l) t += chain[k][8 * q + l][s];
+            g[q] = t;
+          }
+          double ws = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
+          row[1 + s] = (v == 0) ? ws : row[1 + s] + ws;
+        }
+      }
+    }
+  }
+  for (int k = 0; k < K; ++k) {
+    double* m = moments + k * ORC_NMOM;
+    for (int s = 0; s <= NS; ++s) {
+      double part[16];
+      int ng = VS < 16 ? VS : 16;
+      for (int g = 0; g < ng; ++g) {
+        double t = 0.0;
+        for (int q = g; q < VS; q += 16) t += rows[((size_t)q * ORC_MAX_K + k) * (NS + 1) + s];
+        part[g] = t;
+      }
+      double tot = part[0];
+      for (int g = 1; g < ng; ++g) tot += part[g];
+      m[s == 0 ? 0 : s + 1] = tot;
+    }
+  }
+  free(rows);
+}
+
 int orc_gmm_waypoint(const orc_config* cfg, uint64_t seed, int waypoint, const double* state,
                      long long first, long long count, long long n_total, double* moments,
                      double* samples_out, int16_t* flags_out, int8_t* comp_out) {
@@ -750,6 +836,9 @@ int orc_gmm_waypoint(const orc_config* cfg, uint64_t seed, int waypoint, const d
     free_pts[k] = (double*)malloc(sizeof(double) * 3 * (size_t)(count > 0 ? count : 1));
     nfree[k] = 0; ncoll[k] = 0;
   }
+  double* all_pts = (double*)malloc(sizeof(double) * 3 * (size_t)(count > 0 ? count : 1));
+  unsigned char* all_hit = (unsigned char*)malloc((size_t)(count > 0 ? count : 1));
+  unsigned char* all_k = (unsigned char*)malloc((size_t)(count > 0 ? count : 1));
   for (long long i = 0; i < count; ++i) {
     double zz[3];
     uint32_t spare;
@@ -767,9 +856,19 @@ int orc_gmm_waypoint(const orc_config* cfg, uint64_t seed, int waypoint, const d
     int hit = orc_collides(pt[0], pt[1], pt[2], cfg->fp, cfg->boxes, cfg->M);
     if (hit) ++ncoll[k];
     else { memcpy(free_pts[k] + 3 * nfree[k], pt, sizeof pt); ++nfree[k]; }
+    memcpy(all_pts + 3 * i, pt, sizeof pt); all_hit[i] = (unsigned char)hit; all_k[i] = (unsigned char)k;
     if (samples_out) memcpy(samples_out + 3 * i, pt, sizeof pt);
     if (flags_out) flags_out[i] = (int16_t)hit;
     if (comp_out) comp_out[i] = (int8_t)k;
+  }
+  if (g_sum_order == 1) {
+    tree_moments(K, count, all_pts, all_hit, all_k, moments);
+    for (int k = 0; k < K; ++k) {
+      moments[k * ORC_NMOM + 1] = (double)ncoll[k];
+      free(free_pts[k]);
+    }
+    free(all_pts); free(all_hit); free(all_k);
+    return 0;
   }
   for (int k = 0; k < K; ++k) {
     double* m = moments + k * ORC_NMOM;
@@ -784,6 +883,7 @@ int orc_gmm_waypoint(const orc_config* cfg, uint64_t seed, int waypoint, const d
     m[2] = sx; m[3] = sy; m[4] = st; m[5] = sxx; m[6] = sxy; m[7] = sxt; m[8] = syy; m[9] = syt; m[10] = stt;
     free(free_pts[k]);
   }
+  free(all_pts); free(all_hit); free(all_k);
   return 0;
 }
 

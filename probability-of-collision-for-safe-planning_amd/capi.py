@@ -45,6 +45,7 @@ SIGNATURES = {
     "pocs_set_option": (C.c_int, [_vp, C.c_int, C.c_longlong]),
     "pocs_set_batch": (C.c_int, [_vp, C.c_int]),
     "pocs_get_batch_probabilities": (C.c_int, [_vp, _dp, C.c_int]),
+    "pocs_select_batch_run": (C.c_int, [_vp, C.c_int]),
     "pocs_set_shard": (C.c_int, [_vp, C.c_longlong, C.c_longlong]),
     "pocs_set_stream": (C.c_int, [_vp, _vp]),
     "pocs_gmm_begin": (C.c_int, [_vp]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "pocs_measure_copy_bandwidth": (C.c_int, [_vp, C.c_longlong, _dp]),
     "pocs_measure_fill_bandwidth": (C.c_int, [_vp, C.c_longlong, _dp]),
     "pocs_get_kernel_time": (C.c_int, [_vp, _dp, C.POINTER(C.c_longlong)]),
+    "pocs_get_sequence_time": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
 }
 
 _lib = None
@@ -121,6 +123,8 @@ def load_library(build=True):
     _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("POCS_LIB") and not hasattr(lib, name):
+            continue                 # tuning only: an A/B build from an older commit may predate an entry point
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
@@ -237,6 +241,10 @@ class Context:
         out = np.zeros(n)
         got = self._chk(self.lib.pocs_get_batch_probabilities(self.h, out.ctypes.data_as(_dp), n))
         return out[:got]
+
+    def select_batch_run(self, run):
+        """The getters (waypoint probabilities, moments, mixture state, samples ...) expose run `run` of the last batch."""
+        self._chk(self.lib.pocs_select_batch_run(self.h, int(run)))
 
     def set_shard(self, first=-1, count=-1):
         """Evaluate global indices [first, first+count); no arguments = the whole range."""
@@ -390,6 +398,13 @@ class Context:
         g = C.c_double()
         self._chk(self.lib.pocs_measure_fill_bandwidth(self.h, nbytes, C.byref(g)))
         return g.value
+
+    def sequence_time(self):
+        """(ms from the first sampling launch to the end of the last, sub-batches in flight side by side) of the last
+        whole-run GMM call under OPT_PROFILE."""
+        ms, g = C.c_double(0.0), C.c_int(1)
+        self._chk(self.lib.pocs_get_sequence_time(self.h, C.byref(ms), C.byref(g)))
+        return ms.value, g.value
 
     def kernel_time(self):
         ms, n = C.c_double(), C.c_longlong()

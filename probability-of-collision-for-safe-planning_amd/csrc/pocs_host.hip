@@ -38,6 +38,13 @@ struct pocs_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
+  // A call of many runs is issued as `groups` sub-batches on streams of their own (gmm_groups): while one
+  // sub-batch is in the tail of a waypoint's launch (the last blocks' slower waves, the serial mixture
+  // advance of its closers, the launch boundary) the others' sampling blocks have the SIMDs.
+  hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr}, ev_seq[2] = {nullptr, nullptr};
+  double seq_ms = 0.0;                   // POCS_OPT_PROFILE: first launch -> last launch's end of the last whole-run call
+  int seq_groups = 1;
   std::string err;
 
   // ---- configuration (what MCSimulator holds, MCSimulator.h:94-136) ----
@@ -60,7 +67,7 @@ struct pocs_ctx {
   std::vector<double> boxes;             // M x 5
   bool have_obstacles = false;           // pocs_set_obstacles / addObstacle / clearObstacles was called at least once
   long long shard_first = -1, shard_count = -1;
-  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0, opt_persistent = 0;
+  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0;
   unsigned long long epoch = 0;          // bumped by every setter; part of the graph cache key
   int batch = 1;                         // independent GMM estimations advanced in lockstep per call
   // run-ahead (POCS_OPT_RUN_AHEAD): with batch == 1 a run* call evaluates the next `run_ahead` runs
@@ -70,6 +77,7 @@ struct pocs_ctx {
   int view = 0;
   int ra_have = 0;                       // runs of the last launch that may still be served (0: none)
   int ra_kind = 0;                       // 1 GMM, 2 MC
+  int last_kind = 0;                     // what the last launch was: 1 GMM, 2 MC
   bool ra_internal = false;              // the last launch was an internal run-ahead batch
   uint64_t batch_base = 0;               // run_index of run 0 of the last launch
   int batch_R = 1;                       // runs in the last launch
@@ -98,6 +106,8 @@ struct pocs_ctx {
   long long ext_moments_len = 0;
   void* h_pin = nullptr;                 // pinned staging: hdr | chain | state0 | moments | total
   size_t h_pin_cap = 0;
+  void* h_copy = nullptr;                // pinned staging of the audit copies (pocs_copy_*, pocs_get_gmm_state): device data
+                                         // reaches caller memory through it, in pieces of POCS_COPY_CHUNK bytes
   bool env_dirty = true, sensor_dirty = true;
 
   hipGraphExec_t graph_gmm = nullptr, graph_mc = nullptr;
@@ -179,44 +189,37 @@ int grid_blocks(long long count, int block, int default_bpc) {
   if (nb > POCS_MAX_BLOCKS) nb = POCS_MAX_BLOCKS;
   return (int)nb;
 }
-// Task geometry of the GMM kernels (pocs_kernels.h): a chunk = one block iteration = TB pairs of
-// samples; a run's `chunks` are cut into `slices` contiguous ranges; task (w, r, j) = slice j of run r
-// at waypoint w = one block of a k_gmm_step launch.
-//   k_gmm_step  The chip takes blocks 256 at a time (one more per CU) and holds 512 of these: a launch
-//               of runs x slices <= 512 blocks runs as one resident set, and a handful over a multiple
-//               of 256 costs a whole extra block time (measured, 20 runs x 10^6 samples: 25 slices =
-//               500 blocks 1.12, 26 slices = 520 blocks 0.91 x 10^11 evals/s).  So: as many slices as
-//               keep runs x slices <= 512 (<= 256 below 8 runs: fewer, fatter blocks amortise head and
-//               tail better when the launch is short anyway).
-//   k_gmm_run   runs the same tasks (so that both kernels give bitwise the same sums) from a queue, on
-//               min(tasks per waypoint, 512) resident blocks; left to itself it would rather have ~2.5 x
-//               512 tasks per waypoint (sweeps: POCS_SLICES).
-// POCS_SLICES / POCS_RUN_BLOCKS override for sweeps.
-struct GmmGeometry { long long chunks; int slices; int blocks; };
-GmmGeometry gmm_geometry(long long count, int runs, int K) {
-  static int forced = -1, forced_blocks = -1;
+// Task geometry of k_gmm_step (pocs_kernels.h): a chunk = one block iteration = TB pairs of samples; a
+// run's `chunks` are cut into VS = 2^vs_shift virtual slices -- a function of the shard's sample count
+// ONLY, the moment sums are defined on them -- and the launch's units (run, virtual slice) are dealt to
+// the blocks `upb` at a time.  The chip takes blocks 256 at a time (one more per CU) and holds 512 of
+// these: `upb` is the smallest number that fits the launch into 512 blocks (256 below 8 runs: fewer,
+// fatter blocks amortise head and tail better when the launch is short anyway), so every block of a launch
+// has the same amount of work whatever the number of runs (20 runs x 256 slices = 512 blocks x 10).
+// POCS_GMM_BLOCKS overrides the block budget for sweeps.
+struct GmmGeometry { long long chunks; int vs_shift; int upb; int blocks; };
+GmmGeometry gmm_geometry(long long count, int runs, int K, int groups = 1) {
+  static int forced = -1;
   if (forced < 0) {
-    const char* e = getenv("POCS_SLICES");
+    const char* e = getenv("POCS_GMM_BLOCKS");
     forced = e ? atoi(e) : 0;
     if (forced < 0 || forced > 4096) forced = 0;
-    const char* b = getenv("POCS_RUN_BLOCKS");                 // sweeps: resident blocks of k_gmm_run
-    forced_blocks = b ? atoi(b) : 0;
-    if (forced_blocks < 0 || forced_blocks > 4096) forced_blocks = 0;
   }
   const int tb = POCS_GMM_BLOCK_OF(K);
   const long long npairs = (count + 1) / 2;
   GmmGeometry g;
   g.chunks = (npairs + tb - 1) / tb;
   if (g.chunks < 1) g.chunks = 1;
-  const int resident = POCS_NUM_CUS * POCS_GMM_BLOCKS_PER_CU;
-  long long want = (runs >= 8 ? resident : POCS_NUM_CUS) / (runs > 0 ? runs : 1);
-  if (forced) want = forced;
-  if (want < 1) want = 1;
-  if (want > g.chunks) want = g.chunks;
-  g.slices = (int)want;
-  const long long tasks = (long long)runs * g.slices;
-  g.blocks = (int)(tasks < resident ? tasks : resident);
-  if (forced_blocks) g.blocks = forced_blocks;
+  g.vs_shift = 0;
+  while ((2LL << g.vs_shift) <= g.chunks && (2 << g.vs_shift) <= POCS_GMM_MAX_VS) ++g.vs_shift;
+  if (runs < 1) runs = 1;
+  const long long units = (long long)runs << g.vs_shift;
+  // (`groups` launches share the chip: each gets its share of the resident blocks)
+  long long budget = (runs * groups >= 8 ? POCS_NUM_CUS * POCS_GMM_BLOCKS_PER_CU : POCS_NUM_CUS) / groups;
+  if (forced) budget = forced;
+  g.upb = (int)((units + budget - 1) / budget);
+  if (g.upb > (1 << g.vs_shift)) g.upb = 1 << g.vs_shift;           // a block's range touches at most two runs
+  g.blocks = (int)((units + g.upb - 1) / g.upb);
   return g;
 }
 int grid_for_mc(long long count, int runs = 1) {                                      // MC kernels, per run
@@ -430,15 +433,17 @@ int gmm_shard(pocs_ctx* c, long long* first, long long* count) {
   *count = c->shard_first >= 0 ? c->shard_count : c->num_gmm;
   if (*first < 0 || *count < 0 || *first + *count > c->num_gmm)
     return fail(c, POCS_E_ARG, "shard [%lld,+%lld) outside numGMMSamples=%lld", *first, *count, c->num_gmm);
+  if (*count > 2147480000LL)        // the kernels' positions inside a shard are 32-bit
+    return fail(c, POCS_E_ARG, "a GMM shard holds at most 2147480000 samples per run (got %lld): shard the run", *count);
   if ((*first & 1) && *count > 0)   // mixture samples 2j, 2j+1 share their random draws: a shard starts on a pair
     return fail(c, POCS_E_ARG, "GMM shard must start at an even sample index (got %lld)", *first);
   return POCS_OK;
 }
 
-// The synchronisation words of one call (pocs_kernels.h): [0] queue head, [1] give-up code, [2..3] pad,
-// [4 .. 4+Rpad) ready[r], then the tickets [R][W]; a block of its own, a multiple of 16 bytes, zeroed
-// by ONE memset node at the head of every call.
-size_t sync_ticket_offset(const pocs_ctx* c) { return POCS_SYNC_READY + (((size_t)c->batch + 3) & ~(size_t)3); }
+// The synchronisation words of one call (pocs_kernels.h): [1] give-up code, [0], [2..3] pad, then the
+// tickets [R][W]; a block of its own, a multiple of 16 bytes, zeroed by ONE memset node at the head of
+// every call.
+size_t sync_ticket_offset(const pocs_ctx*) { return 4; }
 size_t sync_words(const pocs_ctx* c) {
   const size_t n = sync_ticket_offset(c) + (size_t)c->batch * (size_t)(c->W > 0 ? c->W : 1);
   return (n + 3) & ~(size_t)3;
@@ -463,7 +468,7 @@ int gmm_prepare(pocs_ctx* c) {
     if (int r = ensure(c, c->d_moments, W * R * K * POCS_NMOM * sizeof(double))) return r;
   if (c->ext_moments && c->ext_moments_len < (long long)(W * R * K * POCS_NMOM))
     return fail(c, POCS_E_BUFFER, "bound moments buffer too small");
-  if (int r = ensure(c, c->d_partial, R * (size_t)geo.slices * K * POCS_NMOM * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_partial, (R << geo.vs_shift) * K * POCS_NMOM * sizeof(double))) return r;
   if (int r = ensure(c, c->d_ticket, sync_words(c) * sizeof(unsigned))) return r;
   if (c->opt_store) {
     const size_t n = R * (size_t)sample_stride_of(count);
@@ -551,93 +556,10 @@ int gmm_upload_run(pocs_ctx* c) {
   return POCS_OK;
 }
 
-#if defined(POCS_STEP_STAMPS)
-// diagnostic build: one stamp buffer for the process, summarised on stderr after every whole-run call
-static unsigned long long* g_step_dbg = nullptr;
-static size_t g_step_dbg_words = 0;
-static void step_stamps_report(pocs_ctx* c, long long count) {
-  const GmmGeometry geo = gmm_geometry(count, c->batch, c->K);
-  const int W = c->W, R = c->batch, S = geo.slices;
-  std::vector<unsigned long long> h((size_t)W * R * S * 32);
-  if (hipMemcpy(h.data(), g_step_dbg, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
-  double head = 0, body = 0, spread = 0, ticket = 0, close = 0, adv = 0, total = 0, skew = 0;
-  for (int w = 0; w < W; ++w) {
-    unsigned long long t0 = ~0ull, s0max = 0, s1min = ~0ull, s2max = 0, s3max = 0, s4max = 0, s5max = 0;
-    double s2sum = 0, bsum = 0;
-    for (int b = 0; b < R * S; ++b) {
-      const unsigned long long* q = &h[((size_t)w * R * S + b) * 32];
-      t0 = std::min(t0, q[0]); s0max = std::max(s0max, q[0]); s1min = std::min(s1min, q[1]); s2max = std::max(s2max, q[2]);
-      s3max = std::max(s3max, q[3]); s4max = std::max(s4max, q[4]); s5max = std::max(s5max, q[5]);
-      s2sum += (double)(q[2] - t0 > (1ull << 40) ? 0 : q[2]); bsum += (double)(q[2] - q[1]);
-    }
-    const double mean2 = s2sum / (R * S);
-    skew += (s0max - t0) * 0.01; head += (s1min - t0) * 0.01; body += bsum / (R * S) * 0.01; spread += ((double)s2max - mean2) * 0.01;
-    ticket += (s3max - s2max) * 0.01; close += (s4max > s3max ? (s4max - s3max) * 0.01 : 0); adv += (s5max > s4max ? (s5max - s4max) * 0.01 : 0);
-    total += ((w + 1 < W ? s5max : s3max) - t0) * 0.01;
-  }
-  {   // one waypoint in detail: every block's phases, and the body time by XCD / CU
-    const int w = W / 2;
-    double b1 = 0, dr = 0, tk = 0;
-    std::map<int, std::pair<double, int>> by_xcc, by_cu;
-    std::vector<double> bodies;
-    for (int b = 0; b < R * S; ++b) {
-      const unsigned long long* q = &h[((size_t)w * R * S + b) * 32];
-      b1 += (q[6] - q[2]) * 0.01; dr += (q[7] - q[6]) * 0.01; tk += (q[3] - q[7]) * 0.01;
-      const double body = (q[2] - q[1]) * 0.01;
-      bodies.push_back(body);
-      const int xcc = (int)(q[9] & 15), cu = (int)((q[8] >> 8) & 15), se = (int)((q[8] >> 13) & 7);
-      by_xcc[xcc].first += body; by_xcc[xcc].second++;
-      by_cu[se * 16 + cu].first += body; by_cu[se * 16 + cu].second++;
-    }
-    {   // the block's eight waves: when each finished its body (after the block's body start), by wave index and by SIMD
-      double by_wave[8] = {0}, by_simd[4] = {0}, first_last = 0; int n_simd[4] = {0}; int simd_of[8] = {0};
-      double by_half[2] = {0}; int n_half[2] = {0};
-      for (int b = 0; b < R * S; ++b) {
-        const unsigned long long* q = &h[((size_t)w * R * S + b) * 32];
-        unsigned long long lo = ~0ull, hi = 0;
-        for (int v = 0; v < 8; ++v) {
-          const double t = (q[10 + v] - q[1]) * 0.01;
-          by_wave[v] += t; const int sd = (int)((q[18 + v] >> 4) & 3); by_simd[sd] += t; n_simd[sd]++; if (b == 0) simd_of[v] = sd;
-          lo = std::min(lo, q[10 + v]); hi = std::max(hi, q[10 + v]);
-        }
-        first_last += (hi - lo) * 0.01;
-        by_half[(b >> 8) & 1] += (hi - q[1]) * 0.01; n_half[(b >> 8) & 1]++;
-      }
-      fprintf(stderr, "[step stamps]   a block's waves, body end after body start (us), by wave:");
-      for (int v = 0; v < 8; ++v) fprintf(stderr, " w%d(simd %d) %.1f", v, simd_of[v], by_wave[v] / (R * S));
-      fprintf(stderr, " | by SIMD:");
-      for (int sd = 0; sd < 4; ++sd) fprintf(stderr, " %.1f", by_simd[sd] / std::max(n_simd[sd], 1));
-      fprintf(stderr, " | first -> last wave of a block %.2f | slowest wave, blocks 0-255: %.1f, blocks 256-511: %.1f\n", first_last / (R * S),
-              by_half[0] / std::max(n_half[0], 1), by_half[1] / std::max(n_half[1], 1));
-    }
-    std::sort(bodies.begin(), bodies.end());
-    fprintf(stderr, "[step stamps] waypoint %d: wave 0 body end -> block barrier %.2f us | row + drain + barrier %.2f | ticket + barrier %.2f | body min %.1f p10 %.1f median %.1f p90 %.1f max %.1f\n",
-            w, b1 / (R * S), dr / (R * S), tk / (R * S), bodies.front(), bodies[bodies.size() / 10], bodies[bodies.size() / 2], bodies[bodies.size() * 9 / 10], bodies.back());
-    fprintf(stderr, "[step stamps]   body by XCD:");
-    for (auto& kv : by_xcc) fprintf(stderr, " %d: %.1f (%d)", kv.first, kv.second.first / kv.second.second, kv.second.second);
-    fprintf(stderr, "\n[step stamps]   body by SE.CU:");
-    for (auto& kv : by_cu) fprintf(stderr, " %d.%d: %.1f (%d)", kv.first / 16, kv.first % 16, kv.second.first / kv.second.second, kv.second.second);
-    fprintf(stderr, "\n");
-  }
-  {   // the advance in the closing blocks: staging, the K components (lanes of wave 0), the wait for the counts wave, publishing
-    double st = 0, comp = 0, wait = 0, fin = 0; int n = 0;
-    for (int w = 0; w + 1 < W; ++w)
-      for (int b = 0; b < R * S; ++b) {
-        const unsigned long long* q = &h[((size_t)w * R * S + b) * 32];
-        if (q[5] == 0 || q[26] == 0) continue;                 // not the closer of its run
-        st += (q[26] - q[4]) * 0.01; comp += (q[27] - q[26]) * 0.01; wait += (q[28] - q[27]) * 0.01; fin += (q[5] - q[28]) * 0.01; ++n;
-      }
-    if (n) fprintf(stderr, "[step stamps]   advance in %d closers (us): staging %.2f | components (wave 0) %.2f | -> counts wave done %.2f | normalise + publish %.2f\n",
-                   n, st / n, comp / n, wait / n, fin / n);
-  }
-  fprintf(stderr, "[step stamps] R=%d S=%d per waypoint (us): start skew %.2f | head (first body start) %.2f | body mean %.2f | last body end - mean %.2f | "
-          "-> all tickets %.2f | close_sums %.2f | advance %.2f | first start -> last stamp %.2f\n",
-          R, S, skew / W, head / W, body / W, spread / W, ticket / W, close / W, adv / W, total / W);
-}
-#endif
-
-void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long count, int w) {
+void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long count, int w,
+                     int run_lo = 0, int run_cnt = -1, int groups = 1) {
   memset(a, 0, sizeof *a);
+  if (run_cnt < 0) run_cnt = c->batch;
   a->hdr = (const pocs_run_header*)c->d_hdr.p;
   a->env = (const pocs_env_dev*)c->d_env.p;
   a->tables = (const pocs_tables*)c->d_tables.p;
@@ -649,8 +571,9 @@ void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long
   a->partial = (double*)c->d_partial.p;
   a->sync = (unsigned*)c->d_ticket.p;
   a->ticket = a->sync + sync_ticket_offset(c);
-  const GmmGeometry geo = gmm_geometry(count, c->batch, c->K);
-  a->slices = geo.slices; a->chunks = geo.chunks;
+  const GmmGeometry geo = gmm_geometry(count, run_cnt, c->K, groups);
+  a->chunks = geo.chunks; a->vs_shift = geo.vs_shift; a->upb = geo.upb; a->blocks = geo.blocks;
+  a->run_lo = run_lo; a->run_cnt = run_cnt;
   a->x = (double*)c->d_sx.p; a->y = (double*)c->d_sy.p; a->th = (double*)c->d_st.p;
   a->flags = (int16_t*)c->d_flags.p;
   a->first = first; a->count = count; a->n_total = c->num_gmm;
@@ -658,18 +581,6 @@ void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long
   a->waypoint = w; a->store = c->opt_store ? 1 : 0;
   a->sample_stride = sample_stride_of(count);
   a->nruns = c->batch; a->W = c->W;
-#if defined(POCS_STEP_STAMPS)
-  {
-    const size_t words = (size_t)c->W * c->batch * geo.slices * 32;
-    if (words > g_step_dbg_words) {
-      if (g_step_dbg) (void)hipFree(g_step_dbg);
-      (void)hipMalloc((void**)&g_step_dbg, words * 8);
-      (void)hipMemset(g_step_dbg, 0, words * 8);
-      g_step_dbg_words = words;
-    }
-    a->dbg = g_step_dbg;
-  }
-#endif
 }
 
 // state/param[w] from state/moments[w-1]: its own tiny launch for waypoint 0 and, when sharded,
@@ -681,13 +592,15 @@ int enqueue_advance(pocs_ctx* c, int w) {
   return POCS_OK;
 }
 
-int enqueue_step(pocs_ctx* c, long long first, long long count, int w, bool advance_in_tail, int prof_slot) {
+int enqueue_step(pocs_ctx* c, long long first, long long count, int w, bool advance_in_tail, int prof_slot,
+                 hipStream_t stream = nullptr, int run_lo = 0, int run_cnt = -1, int groups = 1) {
   pocs_gmm_launch a;
-  fill_gmm_launch(c, &a, first, count, w);
+  if (!stream) stream = c->stream;
+  fill_gmm_launch(c, &a, first, count, w, run_lo, run_cnt, groups);
   a.advance_in_tail = (advance_in_tail && w + 1 < c->W) ? 1 : 0;
-  if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot], c->stream));
-  HIPCHK(c, pocs_launch_gmm_step(c->K, a, c->stream));
-  if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot + 1], c->stream));
+  if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot], stream));
+  HIPCHK(c, pocs_launch_gmm_step(c->K, a, stream));
+  if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot + 1], stream));
   return POCS_OK;
 }
 
@@ -696,35 +609,52 @@ int enqueue_ticket_reset(pocs_ctx* c) {
   return POCS_OK;
 }
 
-// k_gmm_run (the whole run in one queue-driven launch) or one k_gmm_step per waypoint?  Same tasks, same
-// arithmetic, bitwise the same results; which is faster is a matter of latency.  Measured on MI355X at the
-// end of round 2 (10^6 samples, K = 3, same box): 64 runs per call 1.40 (k_gmm_run) vs 1.46 x 10^11
-// evals/s; 20 runs 1.06 vs 1.25; 8 runs 0.70 vs 1.05; 1 run 0.17 vs 0.31.  While the chip streams samples
-// at 3+ TB/s a memory round trip inside the launch costs ~3 us instead of ~1, and closing a run's waypoint
-// takes a dozen of them in a row (ticket, acquire, the run's partial rows, the mixture's inputs, its
-// stores, `ready`, and the same again on the side that waits for it) -- with fewer than ~50 runs in flight
-// that chain, not the sampling, sets the pace.  The per-waypoint form pays them on an idle chip.  Hence:
-// k_gmm_step by default, k_gmm_run behind POCS_OPT_PERSISTENT.
-bool use_persistent(const pocs_ctx* c) { return c->opt_persistent != 0 && !c->ext_moments; }
 // How many launches of the hot kernel one whole-run call makes (what POCS_OPT_PROFILE brackets).
-size_t gmm_hot_launches(const pocs_ctx* c) { return use_persistent(c) ? 1 : (size_t)c->W; }
+size_t gmm_hot_launches(const pocs_ctx* c) { return (size_t)c->W; }
 
-int enqueue_gmm_all(pocs_ctx* c, long long first, long long count, bool prof) {
-  const int W = c->W;
-  if (int r = enqueue_ticket_reset(c)) return r;
-  if (int r = enqueue_advance(c, 0)) return r;
-  if (use_persistent(c)) {
-    // the whole run in ONE launch (k_gmm_run): tasks from a queue, the waypoint dependency of a run
-    // carried by its `ready` word
-    pocs_gmm_launch a;
-    fill_gmm_launch(c, &a, first, count, 0);
-    if (prof) HIPCHK(c, hipEventRecord(c->events[0], c->stream));
-    HIPCHK(c, pocs_launch_gmm_run(c->K, gmm_geometry(count, c->batch, c->K).blocks, a, c->stream));
-    if (prof) HIPCHK(c, hipEventRecord(c->events[1], c->stream));
-  } else {
-    for (int w = 0; w < W; ++w)
-      if (int r = enqueue_step(c, first, count, w, true, prof ? w : -1)) return r;
+// Sub-batches of a whole-run call (above): two from 16 runs per call on (each then still fills its half of the
+// resident blocks evenly), one below.  The moment sums do not depend on the launch shape (pocs_kernels.hip,
+// "summation tree"), so the split changes no bit of any result.  POCS_GMM_GROUPS overrides (sweeps: 1..4).
+int gmm_groups(const pocs_ctx* c) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("POCS_GMM_GROUPS");
+    forced = e ? atoi(e) : 0;
+    if (forced < 0 || forced > 4) forced = 0;
   }
+  if (c->ext_moments) return 1;
+  int g = forced ? forced : (c->batch >= 16 ? 2 : 1);
+  if (g > c->batch) g = c->batch;
+  return g;
+}
+
+// The launches of a whole-run call: what the hipGraph holds.  KERNEL NODES ONLY -- the ticket reset ahead of
+// them and the result copies behind them are plain stream operations (enqueue_gmm_results).  On ROCm 7.2 a
+// captured graph that also held the memset and the two device-to-host copies went stale between replays: after
+// a few dozen small synchronous copies plus a large one on the null stream (a caller reading mixture states
+// and samples back between two runs), the next replay's memset no longer cleared the tickets and its kernels
+// ran on garbage -- reproduced with round 2's library, gone with kernel-only graphs (tests/test_gpu_parity.py
+// ::test_graph_replays_survive_readbacks).
+int enqueue_gmm_all(pocs_ctx* c, long long first, long long count, bool prof) {
+  const int W = c->W, R = c->batch, G = gmm_groups(c);
+  if (int r = enqueue_advance(c, 0)) return r;
+  if (prof) HIPCHK(c, hipEventRecord(c->ev_seq[0], c->stream));
+  if (G > 1) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  for (int g = 1; g < G; ++g) HIPCHK(c, hipStreamWaitEvent(c->side_stream[g - 1], c->ev_fork, 0));
+  for (int w = 0; w < W; ++w)
+    for (int g = 0; g < G; ++g) {                    // sub-batch g = runs [g R / G, (g + 1) R / G); events bracket sub-batch 0's launches
+      const int lo = (int)((long long)g * R / G), hi = (int)((long long)(g + 1) * R / G);
+      if (int r = enqueue_step(c, first, count, w, true, (prof && g == 0) ? w : -1, g == 0 ? c->stream : c->side_stream[g - 1], lo, hi - lo, G)) return r;
+    }
+  for (int g = 1; g < G; ++g) {
+    HIPCHK(c, hipEventRecord(c->ev_join[g - 1], c->side_stream[g - 1]));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[g - 1], 0));
+  }
+  if (prof) HIPCHK(c, hipEventRecord(c->ev_seq[1], c->stream));
+  return POCS_OK;
+}
+int enqueue_gmm_results(pocs_ctx* c) {
+  const int W = c->W;
   const PinLayout pl = pin_layout(c);
   HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.moments, moments_dev(c),
                            (size_t)W * c->batch * c->K * POCS_NMOM * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -753,6 +683,7 @@ void gmm_select_view(pocs_ctx* c, int v) {
 void gmm_combine(pocs_ctx* c, const double* moments, double* probability) {
   const int W = c->W, K = c->K, R = c->batch;          // moments: [W][R][K*11]
   c->batch_R = R;
+  c->last_kind = 1;
   c->batch_moments.assign(moments, moments + (size_t)W * R * K * POCS_NMOM);
   c->batch_probs.assign(R, 0.0);
   for (int r = 0; r < R; ++r) {
@@ -772,8 +703,8 @@ void gmm_combine(pocs_ctx* c, const double* moments, double* probability) {
 
 std::string config_key(const pocs_ctx* c, long long first, long long count, const char* tag) {
   char buf[256];
-  snprintf(buf, sizeof buf, "%s e%llu W%d K%d R%d n%lld f%lld c%lld s%lld fu%lld pe%lld st%p em%p", tag, c->epoch,
-           c->W, c->K, c->batch, c->num_gmm, first, count, c->opt_store, c->opt_fused, c->opt_persistent,
+  snprintf(buf, sizeof buf, "%s e%llu W%d K%d R%d g%d n%lld f%lld c%lld s%lld fu%lld st%p em%p", tag, c->epoch,
+           c->W, c->K, c->batch, gmm_groups(c), c->num_gmm, first, count, c->opt_store, c->opt_fused,
            (void*)c->stream, (void*)c->ext_moments);
   return buf;
 }
@@ -792,6 +723,7 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
   lap("upload enqueued");
   const bool prof = c->opt_profile != 0;
   if (int r = prof_begin(c, gmm_hot_launches(c))) return r;
+  if (int r = enqueue_ticket_reset(c)) return r;
   if (c->opt_graph && !prof) {
     const std::string key = config_key(c, first, count, "gmm");
     if (!c->graph_gmm || key != c->graph_gmm_key) {
@@ -811,23 +743,26 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
   } else {
     if (int r = enqueue_gmm_all(c, first, count, prof)) return r;
   }
+  if (int r = enqueue_gmm_results(c)) return r;
   lap("launched");
   prefetch_next_batch(c);          // host chains of the next batch, while the GPU works on this one
   lap("next batch prepared");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   lap("synchronised");
   if (int r = prof_collect(c, gmm_hot_launches(c))) return r;
+  if (prof) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_seq[0], c->ev_seq[1]));
+    c->seq_ms = ms; c->seq_groups = gmm_groups(c);
+  }
   {
     unsigned gave_up = 0;
     memcpy(&gave_up, (double*)c->h_pin + pin_layout(c).total + c->batch + 1, sizeof gave_up);
-    if (gave_up) return fail(c, POCS_E_DEVICE, "k_gmm_run: a bounded wait expired (code %u); results discarded", gave_up);
+    if (gave_up) return fail(c, POCS_E_DEVICE, "a bounded wait expired on the device (code %u); results discarded", gave_up);
   }
   gmm_combine(c, (double*)c->h_pin + pin_layout(c).moments, probability);
   c->last_gmm_count = count;
   c->last_gmm_wp = c->W - 1;
-#if defined(POCS_STEP_STAMPS)
-  step_stamps_report(c, count);
-#endif
   lap("combined");
   return POCS_OK;
 }
@@ -863,7 +798,6 @@ int enqueue_mc_all(pocs_ctx* c, long long first, long long count, bool prof) {
   if (const char* e = getenv("POCS_MC_NT")) a.nontemporal = atoi(e) ? 1 : 0;          // sweeps
   a.mu0[0] = c->traj[0]; a.mu0[1] = c->traj[W]; a.mu0[2] = c->traj[2 * W];
   if (!pocs_chol3_lower(c->cov0, a.L0)) return fail(c, POCS_E_ARG, "initial covariance is not positive definite");
-  HIPCHK(c, hipMemsetAsync(c->d_total.p, 0, (size_t)R * sizeof(unsigned long long), c->stream));
   if (c->opt_fused) {
     a.step = W - 1;
     if (prof) HIPCHK(c, hipEventRecord(c->events[0], c->stream));
@@ -880,9 +814,6 @@ int enqueue_mc_all(pocs_ctx* c, long long first, long long count, bool prof) {
     }
   }
   HIPCHK(c, pocs_launch_mc_count(nblk, a, c->stream));
-  const PinLayout pl = pin_layout(c);
-  HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.total, c->d_total.p, (size_t)R * sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, c->stream));
   return POCS_OK;
 }
 
@@ -906,6 +837,9 @@ int run_mc_local(pocs_ctx* c) {
   const bool prof = c->opt_profile != 0;
   const size_t nprof = c->opt_fused ? 1 : (W > 1 ? W - 1 : 0);
   if (int r = prof_begin(c, nprof > 0 ? nprof : 1)) return r;
+  // (the counter reset ahead of the launches and the result copy behind them are plain stream operations: the
+  // captured graph holds kernel nodes only, like the GMM path's)
+  HIPCHK(c, hipMemsetAsync(c->d_total.p, 0, R * sizeof(unsigned long long), c->stream));
   if (c->opt_graph && !prof) {
     const std::string key = config_key(c, first, count, "mc") + std::to_string(c->num_particles);
     if (!c->graph_mc || key != c->graph_mc_key) {
@@ -925,13 +859,16 @@ int run_mc_local(pocs_ctx* c) {
   } else {
     if (int r = enqueue_mc_all(c, first, count, prof)) return r;
   }
+  const PinLayout pl = pin_layout(c);
+  HIPCHK(c, hipMemcpyAsync((double*)c->h_pin + pl.total, c->d_total.p, R * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, c->stream));
   prefetch_next_batch(c);          // host chains of the next batch, while the GPU works on this one
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (int r = prof_collect(c, nprof)) return r;
-  const PinLayout pl = pin_layout(c);
   c->mc_counts.resize(R);
   memcpy(c->mc_counts.data(), (double*)c->h_pin + pl.total, R * sizeof(unsigned long long));
   c->last_mc_count = count;
+  c->last_kind = 2;
   return POCS_OK;
 }
 
@@ -1013,21 +950,42 @@ int pocs_create(pocs_ctx** out, int device) {
   HIPCHK(c, hipSetDevice(device));
   HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
+  for (int g = 0; g < 3; ++g) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream[g], hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming));
+  }
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreate(&c->ev_seq[0]));
+  HIPCHK(c, hipEventCreate(&c->ev_seq[1]));
   return POCS_OK;
 }
 
+#if defined(POCS_STAMPS)
+void pocs_stamps_report();
+#endif
 void pocs_destroy(pocs_ctx* c) {
   if (!c) return;
+#if defined(POCS_STAMPS)
+  if (c->own_stream) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); pocs_stamps_report(); }
+#endif
   if (c->own_stream) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     drop_graphs(c);
     for (hipEvent_t e : c->events) hipEventDestroy(e);
+    for (int g = 0; g < 3; ++g) {
+      if (c->side_stream[g]) { hipStreamSynchronize(c->side_stream[g]); hipStreamDestroy(c->side_stream[g]); }
+      if (c->ev_join[g]) hipEventDestroy(c->ev_join[g]);
+    }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_seq[0]) hipEventDestroy(c->ev_seq[0]);
+    if (c->ev_seq[1]) hipEventDestroy(c->ev_seq[1]);
     DevBuf* all[] = {&c->d_env, &c->d_sensor, &c->d_hdr, &c->d_chain, &c->d_state, &c->d_param,
                      &c->d_moments, &c->d_partial, &c->d_sx, &c->d_sy, &c->d_st, &c->d_flags,
                      &c->d_px, &c->d_py, &c->d_pt, &c->d_hits, &c->d_total, &c->d_ticket, &c->d_tables};
     for (DevBuf* b : all) if (b->p) hipFree(b->p);
     if (c->h_pin) hipHostFree(c->h_pin);
+    if (c->h_copy) hipHostFree(c->h_copy);
     for (int q = 0; q < POCS_XCHG_MAX_WORLD; ++q)
       if (c->xchg_peer[q] && c->xchg_peer[q] != c->xchg_own) (void)hipIpcCloseMemHandle(c->xchg_peer[q]);
     if (c->xchg_own) (void)hipFree(c->xchg_own);
@@ -1173,7 +1131,11 @@ int pocs_set_option(pocs_ctx* c, int option, long long value) {
     case POCS_OPT_MC_FUSED: c->opt_fused = value ? 1 : 0; break;
     case POCS_OPT_USE_GRAPH: c->opt_graph = value ? 1 : 0; break;
     case POCS_OPT_PROFILE: c->opt_profile = value ? 1 : 0; break;
-    case POCS_OPT_PERSISTENT: c->opt_persistent = value ? 1 : 0; break;
+    case POCS_OPT_PERSISTENT:
+      // the queue-driven whole-call kernel (k_gmm_run) of round 2 was retired in round 3: slower than one launch per
+      // waypoint at every batch size measured, and not worth a second summation shape
+      if (value) return fail(c, POCS_E_ARG, "POCS_OPT_PERSISTENT: the queue-driven kernel has been retired (DESIGN.md section 5)");
+      break;
     case POCS_OPT_RUN_AHEAD:
       if (value < 0 || value > 256) return fail(c, POCS_E_ARG, "run-ahead %lld outside 0..256", value);
       c->run_ahead = (int)value;                     // 0 = sized per call (ra_depth)
@@ -1202,6 +1164,15 @@ int pocs_get_batch_probabilities(pocs_ctx* c, double* out, int cap) {
   if ((int)c->batch_probs.size() > cap) return fail(c, POCS_E_BUFFER, "need %zu doubles", c->batch_probs.size());
   memcpy(out, c->batch_probs.data(), c->batch_probs.size() * sizeof(double));
   return (int)c->batch_probs.size();
+}
+
+int pocs_select_batch_run(pocs_ctx* c, int run) {
+  if (!c) return POCS_E_ARG;
+  if (c->ra_internal) return fail(c, POCS_E_ORDER, "pocs_select_batch_run: the last launch was a run-ahead batch (one run per command)");
+  if (run < 0 || run >= c->batch_R || c->batch_probs.empty()) return fail(c, POCS_E_ARG, "run %d outside the last batch (0..%d)", run, c->batch_R - 1);
+  if (c->last_kind == 1) gmm_select_view(c, run);       // per-waypoint probabilities and moments of that run
+  c->view = run;
+  return POCS_OK;
 }
 
 int pocs_set_shard(pocs_ctx* c, long long first, long long count) {
@@ -1420,6 +1391,7 @@ int pocs_gmm_exchange_local(pocs_ctx* c, int w) {
   for (int q = 0; q < c->xchg_world; ++q) x.buf[q] = (double*)c->xchg_peer[q];
   x.world = c->xchg_world; x.rank = c->xchg_rank;
   x.epoch = (c->xchg_calls << 20) | (unsigned long long)(w + 1);
+  x.parity = (int)((c->xchg_calls * (unsigned long long)c->W + (unsigned long long)w) & 1ull);
   HIPCHK(c, pocs_launch_gmm_exchange(c->K, a, x, c->stream));
   if (w + 1 < c->W) c->last_gmm_adv = w + 1;          // the exchange launch has built the mixture of w + 1
   return POCS_OK;
@@ -1444,6 +1416,7 @@ int pocs_gmm_sample_exchange_local(pocs_ctx* c, int w) {
   for (int q = 0; q < c->xchg_world; ++q) a.xchg.buf[q] = (double*)c->xchg_peer[q];
   a.xchg.world = c->xchg_world; a.xchg.rank = c->xchg_rank;
   a.xchg.epoch = (c->xchg_calls << 20) | (unsigned long long)(w + 1);
+  a.xchg.parity = (int)((c->xchg_calls * (unsigned long long)c->W + (unsigned long long)w) & 1ull);
   const int slot = c->opt_profile ? w : -1;
   if (slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * slot], c->stream));
   HIPCHK(c, pocs_launch_gmm_step(c->K, a, c->stream));
@@ -1495,6 +1468,8 @@ int pocs_get_moments(pocs_ctx* c, int w, double* out, int cap) {
   return n;
 }
 
+static int copy_out(pocs_ctx* c, void* dst, const void* src_dev, size_t bytes, size_t elem, size_t dst_stride);
+
 int pocs_get_gmm_state(pocs_ctx* c, int w, double* means3, double* covs9, double* weights, double* alive) {
   if (!c) return POCS_E_ARG;
   if (w < 0 || w > c->last_gmm_wp || !c->d_state.p) return fail(c, POCS_E_ARG, "no mixture for waypoint %d", w);
@@ -1502,7 +1477,7 @@ int pocs_get_gmm_state(pocs_ctx* c, int w, double* means3, double* covs9, double
   std::vector<double> s((size_t)c->K * POCS_STATE_STRIDE);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const double* run_state = (double*)c->d_state.p + (size_t)c->view * c->W * s.size();    // [run][W][K*16]
-  HIPCHK(c, hipMemcpy(s.data(), run_state + (size_t)w * s.size(), s.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (int r = copy_out(c, s.data(), run_state + (size_t)w * s.size(), s.size() * sizeof(double), 1, 0)) return r;
   for (int k = 0; k < c->K; ++k) {
     if (means3) memcpy(means3 + 3 * k, &s[(size_t)k * POCS_STATE_STRIDE], 3 * sizeof(double));
     if (covs9) memcpy(covs9 + 9 * k, &s[(size_t)k * POCS_STATE_STRIDE + 3], 9 * sizeof(double));
@@ -1529,15 +1504,25 @@ int pocs_get_host_chain(pocs_ctx* c, double* applied3, double* noisy3, double* z
   return steps;
 }
 
+// Device -> caller memory through the context's own pinned staging buffer, a piece at a time (the runtime
+// would otherwise pin the caller's pageable pages on the fly for every call).
+#define POCS_COPY_CHUNK (4u << 20)
+static int copy_out(pocs_ctx* c, void* dst, const void* src_dev, size_t bytes, size_t elem, size_t dst_stride) {
+  if (!c->h_copy) HIPCHK(c, hipHostMalloc(&c->h_copy, POCS_COPY_CHUNK, hipHostMallocDefault));
+  for (size_t off = 0; off < bytes; off += POCS_COPY_CHUNK) {
+    const size_t n = bytes - off < POCS_COPY_CHUNK ? bytes - off : POCS_COPY_CHUNK;
+    HIPCHK(c, hipMemcpy(c->h_copy, (const char*)src_dev + off, n, hipMemcpyDeviceToHost));
+    if (dst_stride == 0) memcpy((char*)dst + off, c->h_copy, n);
+    else                                             // scatter elements of `elem` bytes `dst_stride` bytes apart
+      for (size_t i = 0; i < n / elem; ++i) memcpy((char*)dst + (off / elem + i) * dst_stride, (const char*)c->h_copy + i * elem, elem);
+  }
+  return POCS_OK;
+}
 static long long copy_soa_as_aos(pocs_ctx* c, const DevBuf& bx, const DevBuf& by, const DevBuf& bt,
                                  size_t first, long long n, double* aos) {
-  std::vector<double> tmp((size_t)n);
   const DevBuf* src[3] = {&bx, &by, &bt};
-  for (int j = 0; j < 3; ++j) {
-    if (hipMemcpy(tmp.data(), (const double*)src[j]->p + first, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    for (long long i = 0; i < n; ++i) aos[3 * i + j] = tmp[(size_t)i];
-  }
-  (void)c;
+  for (int j = 0; j < 3; ++j)
+    if (copy_out(c, aos + j, (const double*)src[j]->p + first, (size_t)n * sizeof(double), sizeof(double), 3 * sizeof(double)) != POCS_OK) return -1;
   return n;
 }
 
@@ -1550,7 +1535,7 @@ long long pocs_copy_gmm_samples(pocs_ctx* c, double* aos, int16_t* flags, long l
     return fail(c, POCS_E_DEVICE, "sync failed");
   const size_t off = (size_t)c->view * (size_t)sample_stride_of(n);          // this run's slice
   if (aos && copy_soa_as_aos(c, c->d_sx, c->d_sy, c->d_st, off, n, aos) < 0) return fail(c, POCS_E_DEVICE, "copy failed");
-  if (flags && hipMemcpy(flags, (const int16_t*)c->d_flags.p + off, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost) != hipSuccess)
+  if (flags && copy_out(c, flags, (const int16_t*)c->d_flags.p + off, (size_t)n * sizeof(int16_t), 1, 0) != POCS_OK)
     return fail(c, POCS_E_DEVICE, "copy failed");
   return n;
 }
@@ -1564,7 +1549,7 @@ long long pocs_copy_particles(pocs_ctx* c, double* aos, uint32_t* hits, long lon
     return fail(c, POCS_E_DEVICE, "sync failed");
   const size_t off = (size_t)c->view * (size_t)sample_stride_of(n);          // this run's slice
   if (aos && copy_soa_as_aos(c, c->d_px, c->d_py, c->d_pt, off, n, aos) < 0) return fail(c, POCS_E_DEVICE, "copy failed");
-  if (hits && hipMemcpy(hits, (const uint32_t*)c->d_hits.p + off, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+  if (hits && copy_out(c, hits, (const uint32_t*)c->d_hits.p + off, (size_t)n * sizeof(uint32_t), 1, 0) != POCS_OK)
     return fail(c, POCS_E_DEVICE, "copy failed");
   return n;
 }
@@ -1625,6 +1610,13 @@ int pocs_measure_fill_bandwidth(pocs_ctx* c, long long bytes, double* gbps) {
   (void)hipFree(a);
   *gbps = best;
   return rc;
+}
+
+int pocs_get_sequence_time(pocs_ctx* c, double* ms, int* concurrent) {
+  if (!c) return POCS_E_ARG;
+  if (ms) *ms = c->seq_ms;
+  if (concurrent) *concurrent = c->seq_groups;
+  return POCS_OK;
 }
 
 int pocs_get_kernel_time(pocs_ctx* c, double* total_ms, long long* launches) {

@@ -25,6 +25,19 @@
 #endif
 #define POCS_NUM_CUS 256
 #define POCS_MAX_BLOCKS 2048
+// Task geometry of k_gmm_step.  A chunk = one iteration of a block = POCS_GMM_BLOCK_OF(K) pairs of samples.
+// A run's chunks are cut into VS = 2^vs_shift VIRTUAL SLICES, slice j = chunks [j * chunks / VS,
+// (j + 1) * chunks / VS): VS depends on the shard's sample count only (the largest power of two <= min(256,
+// chunks)), never on how many runs share the launch -- the moment sums are defined on the virtual slices
+// (pocs_kernels.hip, "summation tree"), which is what makes a run's result independent of the batch.
+// The launch's work = the flat list of units t = r * VS + j; block b takes units [b * upb, (b + 1) * upb).
+#ifndef POCS_GMM_MAX_VS            // (sweeps: a coarser cut changes the sums' last bits)
+#define POCS_GMM_MAX_VS 256
+#endif
+#define POCS_GMM_SUB 32        // units whose wave sums a block holds in LDS at a time (64 runs x 256 slices / 512 blocks)
+#define POCS_UNIT_SUMS 10      // survivors + the nine sums
+#define POCS_FLUSH_ROWS 5      // flush_unit's transpose scratch per wave: 5 rows of 64 lane values,
+#define POCS_FLUSH_PITCH 66    // pitch 66 doubles (16-byte aligned rows, off the bank stride)
 // chain record (doubles), one per step i < W-1:
 //   [0..2] applied control   [3..5] diag of M   [6..8] the noisy control actually driven (MC)
 //   [9] unused               [10 .. 10+L) the L range observations of the step
@@ -58,6 +71,8 @@ struct pocs_run_header {         // per-run scalars read by every kernel (so a c
 struct pocs_xchg_dev {
   double* buf[POCS_XCHG_MAX_WORLD];   // buffer of rank q as mapped in THIS process (own rank: the allocation itself)
   int world, rank;
+  int parity;                         // which of the two slot sets: (exchanges so far) & 1, the same on every rank
+  int pad;
   unsigned long long epoch;           // of this waypoint's rows: (call number << 20) | (waypoint + 1)
 };
 
@@ -72,11 +87,10 @@ struct pocs_gmm_launch {
   double* state;                 // [nruns][W][K*POCS_STATE_STRIDE]  mixture sampled at each waypoint
   double* param;                 // [nruns][W][K*POCS_PARAM_STRIDE]  its sampler parameters (incl. the cumulative component counts)
   double* moments;               // [W][nruns][K*POCS_NMOM]          reduced moments of each waypoint
-  double* partial;               // [nruns][slices][K*POCS_NMOM]     partial row of task (run, slice); reused every waypoint
-  unsigned* sync;                // the call's synchronisation words, zeroed once per call: [0] task queue head,
-                                 // [1] give-up code of a bounded wait (0 = none), [4 + r] `ready` = waypoints of run r
-                                 // whose sampler parameters are published (k_gmm_run)
-  unsigned* ticket;              // [nruns][W] arrival counters of the tasks of (run, waypoint); same zeroed block
+  double* partial;               // [nruns][VS][K*POCS_NMOM]         row of (run, virtual slice); rewritten every waypoint
+  unsigned* sync;                // the call's synchronisation words, zeroed once per call:
+                                 // [1] give-up code of a bounded wait (0 = none)
+  unsigned* ticket;              // [nruns][W] arrival counters of the blocks of (run, waypoint); same zeroed block
   double* x; double* y; double* th;   // SoA sample buffers [nruns][sample_stride] (unused when !store)
   int16_t* flags;
   long long n_total;             // samples of the whole mixture (all shards): what the component counts add up to
@@ -92,17 +106,14 @@ struct pocs_gmm_launch {
   int advance_in_tail;           // 1: the last block also builds state/param[waypoint+1] (single GPU)
   int exchange_in_tail;          // 1: ... after exchanging the run's moments with the other ranks through `xchg` (sharded)
   pocs_xchg_dev xchg;
-  // task geometry: a chunk = POCS_GMM_BLOCK_OF(K) pairs of samples (one iteration of a block); slice j of
-  // a run = chunks [j*chunks/slices, (j+1)*chunks/slices); task (w, r, j) = slice j of run r at waypoint w
-  int slices;
-  long long chunks;
-#if defined(POCS_STEP_STAMPS)          // diagnostic build (tools/step_stamps.sh): where a k_gmm_step launch spends its time
-  unsigned long long* dbg;       // [W][nruns][slices][32] wall-clock stamps (100 MHz) of each block
-#endif
+  // task geometry (above)
+  long long chunks;              // of the shard
+  int vs_shift;                  // VS = 1 << vs_shift virtual slices per run
+  int upb;                       // units per block (<= VS)
+  int blocks;                    // ceil(run_cnt * VS / upb)
+  int run_lo, run_cnt;           // the runs of the batch this launch works on
 };
-#define POCS_SYNC_HEAD 0
 #define POCS_SYNC_ABORT 1
-#define POCS_SYNC_READY 4
 
 struct pocs_mc_launch {               // blockIdx.y = run of the batch, like pocs_gmm_launch
   const pocs_run_header* hdr;          // [nruns]
@@ -123,8 +134,7 @@ struct pocs_mc_launch {               // blockIdx.y = run of the batch, like poc
 };
 
 
-hipError_t pocs_launch_gmm_step(int K, const pocs_gmm_launch& a, hipStream_t s);              // grid = (a.slices, a.nruns)
-hipError_t pocs_launch_gmm_run(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);    // persistent: all W waypoints
+hipError_t pocs_launch_gmm_step(int K, const pocs_gmm_launch& a, hipStream_t s);              // grid = a.blocks
 hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t s);
 hipError_t pocs_launch_gmm_exchange(int K, const pocs_gmm_launch& a, const pocs_xchg_dev& x, hipStream_t s);   // grid = a.nruns
 hipError_t pocs_launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);

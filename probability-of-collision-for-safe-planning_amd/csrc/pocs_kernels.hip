@@ -1,17 +1,12 @@
 // pocs_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the hot path.
 //
-//   k_gmm_run       S1+C1+T1  the whole of runGMMEstimation's sample work -- all W waypoints of every run
-//                             of a batch -- in ONE launch: the tasks below handed out from a queue, the
-//                             per-run dependency (waypoint w+1 needs the truncated mixture of w) carried
-//                             by a `ready` word per run instead of a launch boundary.
 //   k_gmm_step      S1+C1+T1  one waypoint of truncateGMM (MCSimulator.h:570-642) in ONE launch, for
-//                             every run of a batch of independent estimations (blockIdx.y = run); the
-//                             per-waypoint form for callers that exchange moments in between (multi-GPU).
-//                             A task (both kernels):
+//                             every run of a batch of independent estimations: the launch's units
+//                             (run, virtual slice) dealt evenly to the blocks.  A block:
 //                             head  log/sector tables, obstacle table and this waypoint's sampler
 //                                   parameters -> LDS; exact culling of the obstacle table against
 //                                   the mixture's bounding box, the kept records' broad phase
-//                                   tightened to the task's range of headings;
+//                                   tightened to the run's range of headings;
 //                             body  GM_Model::sampleNPoints (GM_Model.h:83-116) + checkMatrixCollisions
 //                                   (:241-253) + the moment sums (:592-611), fused, one PAIR of
 //                                   samples per thread-iteration: a sample is born, tested and folded
@@ -19,13 +14,15 @@
 //                                   and flag are streamed out once (24 B + 2 B).  A wave whose 128
 //                                   samples lie in one component block (nearly always) runs the
 //                                   iteration's scalar-component form in an inner loop of its own;
-//                             tail  DPP row sums -> LDS -> one write-through partial row per block ->
-//                                   the last block to arrive adds the rows in a fixed order and
-//                                   advances the mixture to the next waypoint: truncated mean/cov,
-//                                   weights (:597-629), per-component EKF predict/update (:766-771,
-//                                   :804-812), Cholesky -- on one GPU right away, sharded after it has
-//                                   exchanged the run's moments with the other ranks (IPC slots, one
-//                                   hop over xGMI) in the same tail.
+//                                   at the end of every virtual slice the wave's lane chains become a
+//                                   wave sum in LDS (transposition, no barrier);
+//                             tail  wave sums -> write-through rows per (run, virtual slice) -> ticket ->
+//                                   the last block of a run to arrive adds the run's rows in a fixed
+//                                   order and advances the mixture to the next waypoint: truncated
+//                                   mean/cov, weights (:597-629), per-component EKF predict/update
+//                                   (:766-771, :804-812), Cholesky -- on one GPU right away, sharded
+//                                   after it has exchanged the run's moments with the other ranks (IPC
+//                                   slots, one hop over xGMI) in the same tail.
 //                             The waypoint loop never returns to the host.
 //   k_gmm_advance   T1 tail   the same mixture advance as its own launch (waypoint 0; after the
 //                             caller's all-reduce when the shards exchange their moments that way).
@@ -45,6 +42,7 @@
 // reproducible run to run (no float atomics).
 #include "pocs_kernels.h"
 #include <type_traits>
+#include <stdio.h>
 
 namespace {
 
@@ -54,8 +52,10 @@ namespace {
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  // (`old` = 0 with bound_ctrl: every lane has a valid source in the patterns used here, so `old` is never
+  // taken, and the compiler need not copy the source to protect it)
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi2, lo2);
 }
 __device__ __forceinline__ double row_sum(double v) {
@@ -120,30 +120,14 @@ __device__ __forceinline__ double load_wt(const double* p) {
   return __longlong_as_double((long long)__hip_atomic_load(
       reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-// The sample stream of k_gmm_run.  One launch covers every waypoint, and a run's sample slice is
-// rewritten at every waypoint by whichever block -- on whichever XCD -- takes the task: with plain or
-// non-temporal stores an older line can still sit dirty in ANOTHER XCD's write-back L2 and reach memory
-// after the newer one (seen: stale first-waypoint samples in the final buffer).  Write-through stores
-// (`sc1`) leave no dirty line behind; each task drains them before it takes its ticket, and the next
-// waypoint's tasks of the run start only behind that, so memory sees the waypoints in order.
-// SGPR base + 32-bit lane offset, as the compiler addresses the same stores.
 typedef double v2d __attribute__((ext_vector_type(2)));
-#ifndef POCS_WT_BITS
-#define POCS_WT_BITS "sc1"
-#endif
-// the same addressing for the per-waypoint kernel's non-temporal stream (the compiler, left to itself,
+// The sample stream: SGPR base + 32-bit lane offset, non-temporal (the compiler, left to itself,
 // builds a 64-bit address per lane and store: four vector adds per iteration)
 __device__ __forceinline__ void store16_nt(const void* base_uniform, unsigned lane_bytes, v2d v) {
   asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_bytes), "v"(v), "s"(base_uniform) : "memory");
 }
 __device__ __forceinline__ void store4_nt(const void* base_uniform, unsigned lane_bytes, int v) {
   asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(lane_bytes), "v"(v), "s"(base_uniform) : "memory");
-}
-__device__ __forceinline__ void store16_wt(const void* base_uniform, unsigned lane_bytes, v2d v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 " POCS_WT_BITS "\n\ts_nop 1" ::"v"(lane_bytes), "v"(v), "s"(base_uniform) : "memory");
-}
-__device__ __forceinline__ void store4_wt(const void* base_uniform, unsigned lane_bytes, int v) {
-  asm volatile("global_store_dword %0, %1, %2 " POCS_WT_BITS ::"v"(lane_bytes), "v"(v), "s"(base_uniform) : "memory");
 }
 // a 64-bit value the program knows to be wave-uniform, pinned into scalar registers
 __device__ __forceinline__ long long uniform64(long long v) {
@@ -158,10 +142,9 @@ __device__ __forceinline__ void acquire_agent() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the invalidate completes before the barrier releases the readers
 }
 
-#if defined(POCS_TASK_STAMPS)     // diagnostic build (tools/task_stamps.sh): where a WAVE of k_gmm_run spends its time
-#include <stdio.h>
-__device__ unsigned long long g_stamps[32];
-#define POCS_STAMP(i) do { const unsigned long long n_ = wall_clock64(); st_[i] += n_ - last_; last_ = n_; } while (0)
+#if defined(POCS_STAMPS)       // diagnostic build (tools/stamps.sh): where the blocks of a k_gmm_step launch spend their time
+__device__ unsigned long long g_stamps[16];
+#define POCS_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_stamps[i], n_ - last_); last_ = n_; } } while (0)
 #else
 #define POCS_STAMP(i) do { } while (0)
 #endif
@@ -172,32 +155,38 @@ __device__ unsigned long long g_stamps[32];
                              (int)(sizeof(pocs_sensor) / sizeof(double)))
 #define POCS_SPEC_SCRATCH(K) ((K) * (POCS_STATE_STRIDE + 2))
 
-// LDS of the GMM kernels.  NB = task buffers: 1 for k_gmm_step (one task per block), 3 for k_gmm_run
-// (the waves of a block drift up to a task apart, see there).
-template <int K, int TB, int NB>
+// LDS of k_gmm_step.  A block works through a contiguous range of the launch's UNITS -- (run, virtual slice)
+// pairs, pocs_kernels.h -- that may cross from one run into the next: everything per run is held twice.
+//   tr     the wave's transpose scratch of flush_unit (5 rows of 64 lane values, pitch 66); before the first
+//          flush the same bytes hold the full obstacle table the culling reads, after the last one the
+//          closer's staging rows (gmm_close_sums)
+//   slot   wave sums (survivors, nine sums) of the unit's FIRST component, per virtual slice held and wave;
+//          once the rows are out, the mixture advance's scratch
+//   xtra   ... of a component that STARTS inside the unit (a wave meets the start of a component once per run)
+template <int K, int TB>
 struct gmm_smem {
   static constexpr int NC = K * POCS_NMOM;
-  static constexpr int RB = TB / 16;                                 // rows of sums per task: one per 16-lane DPP row
+  static constexpr int NW = TB / 64;
+  static constexpr int SUB = POCS_GMM_SUB;
   alignas(16) pocs_tables tab;                                       // 12 KB log / sector tables, staged once per block
-  alignas(16) double obs[POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];      // obstacle table, staged once per block
-  alignas(16) double keep[NB][POCS_MAX_OBSTACLES * POCS_OBS_STRIDE]; // ... culled for a task
-  alignas(16) double par[NB][K * POCS_PARAM_STRIDE];                 // sampler parameters of the task's (run, waypoint)
-  double red[NB][RB][NC];                                            // the task's row sums; staging area of its closer
-  double adv[POCS_ADV_SCRATCH(K)];                                   // mixture advance: inputs and outputs
-  double spec[POCS_SPEC_SCRATCH(K)];
-  double tot[NC];
-  int nkeep[NB];
-  int last;                 // k_gmm_step: this block drew the last ticket
-  // k_gmm_run, the block's task pipeline: buffer b = n % NB holds the block's n-th task
-  unsigned long long seed[NB];      // what every wave needs of it, worked out once by the loader: the run's seed,
-  long long c_begin[NB], c_end[NB]; // its chunk range,
-  int tw[NB], tr[NB], tslot[NB];    // waypoint, run, slice
-  unsigned task_id[NB];     // its number in the launch's queue (>= total: no more tasks, leave)
-  unsigned seq[NB];         // n + 1 once wave 0 has staged it (parameters, culled table)
-  unsigned done[NB];        // waves that have sampled their share of it and drained their stores
-  unsigned freed[NB];       // n + 1 once its closing wave is through with the buffer
-  unsigned lock;            // the advance scratch above is one wave's at a time
-  unsigned quit;            // a bounded wait expired somewhere: everybody leaves
+  alignas(16) double keep[2][POCS_MAX_OBSTACLES * POCS_OBS_STRIDE];  // obstacle table culled for the block's (up to) two runs
+  alignas(16) double par[2][K * POCS_PARAM_STRIDE];                  // sampler parameters of (run, waypoint)
+  alignas(16) double tr[NW][POCS_FLUSH_ROWS][POCS_FLUSH_PITCH];
+  alignas(16) double slot[SUB][NW][POCS_UNIT_SUMS];
+  double xtra[2][NW][K][POCS_UNIT_SUMS];
+  int kf[SUB][NW];                                                   // the component slot[..] belongs to
+  int xj[2][NW][K];                                                  // the held virtual slice xtra[..] belongs to (-1: none)
+  unsigned long long seed[2];                                        // the two runs' seeds
+  int nkeep[2];
+  int last[2];                                                       // this block drew the last ticket of its run 0 / 1
+  static_assert(sizeof(double) * NW * POCS_FLUSH_ROWS * POCS_FLUSH_PITCH >= sizeof(double) * POCS_MAX_OBSTACLES * POCS_OBS_STRIDE,
+                "the obstacle table is staged in the transpose scratch");
+  static_assert(NW * POCS_FLUSH_ROWS * POCS_FLUSH_PITCH >= 16 * NC, "the closer's staging rows live in the transpose scratch");
+  static_assert(SUB * NW * POCS_UNIT_SUMS >= POCS_ADV_SCRATCH(K) + POCS_SPEC_SCRATCH(K), "the advance's scratch lives in the slots");
+  __device__ __forceinline__ double* obs() { return &tr[0][0][0]; }
+  __device__ __forceinline__ double* stage() { return &tr[0][0][0]; }
+  __device__ __forceinline__ double* adv() { return &slot[0][0][0]; }
+  __device__ __forceinline__ double* spec() { return &slot[0][0][0] + POCS_ADV_SCRATCH(K); }
 };
 
 // Mixture bookkeeping of waypoint `w` (pocs_gmm_advance_component / pocs_gmm_normalise): every input
@@ -206,7 +195,7 @@ struct gmm_smem {
 // covariance, EKF predict + update, Cholesky); lane 0 normalises, draws the component counts, and the
 // wave writes state[w] / param[w] back write-through.  Run by a whole block (k_gmm_advance,
 // k_gmm_step: a lane of a second wave draws the counts meanwhile, on the premise -- checked -- that
-// no factorisation fails) or by a single wave (k_gmm_run); same functions, same results.
+// no factorisation fails).
 struct adv_ptrs {
   double *l_prev, *l_mom, *l_ch, *l_sen, *l_next, *l_par;
   double *g_state, *g_param;
@@ -332,34 +321,13 @@ __device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, 
 // The whole advance to waypoint w by a block of >= 128 threads (every thread calls it).
 __device__ __forceinline__ void advance_block(const pocs_gmm_launch& a, int K, int w, int r, double* adv, double* spec,
                                               bool mom_in_lds, int tid, int nthreads) {
-#if defined(POCS_STEP_STAMPS)      // k_gmm_step's closer only (w >= 1 there): where the advance spends its time
-  unsigned long long* const dbg_ = (mom_in_lds && gridDim.y > 1 + 0 * K) || mom_in_lds
-      ? a.dbg + (((size_t)(w - 1) * a.nruns + r) * a.slices + blockIdx.x) * 32 : nullptr;
-#define POCS_ADV_STAMP(i) do { if (dbg_ && tid == 0) dbg_[i] = wall_clock64(); } while (0)
-#else
-#define POCS_ADV_STAMP(i) do { } while (0)
-#endif
   advance_stage(a, K, w, r, adv, mom_in_lds, tid, nthreads);
   __syncthreads();
-  POCS_ADV_STAMP(26);
   if (tid < 64) advance_components(a, K, w, r, tid, adv);
   else if (tid == 64 && w > 0) speculate_counts(a, K, w, r, adv, spec);
-  POCS_ADV_STAMP(27);
   __syncthreads();
-  POCS_ADV_STAMP(28);
   if (tid < 64) advance_finish(a, K, w, r, tid, adv, w > 0 ? spec : nullptr);
 }
-// ... and by ONE wave (all 64 lanes call it), the moments of w-1 already in l_mom.
-__device__ __forceinline__ void advance_wave(const pocs_gmm_launch& a, int K, int w, int r, double* adv, int lane) {
-  advance_stage(a, K, w, r, adv, true, lane, 64);
-  __threadfence_block();
-  __builtin_amdgcn_wave_barrier();
-  advance_components(a, K, w, r, lane, adv);
-  __threadfence_block();
-  __builtin_amdgcn_wave_barrier();
-  advance_finish(a, K, w, r, lane, adv, nullptr);
-}
-
 __global__ __launch_bounds__(128) void k_gmm_advance(pocs_gmm_launch a, int K) {
   __shared__ double s_adv[POCS_ADV_SCRATCH(POCS_MAX_GAUSSIANS)];
   __shared__ double s_spec[POCS_SPEC_SCRATCH(POCS_MAX_GAUSSIANS)];
@@ -375,7 +343,9 @@ __global__ __launch_bounds__(128) void k_gmm_advance(pocs_gmm_launch a, int K) {
 // of EVERY buffer (system-scope stores: peers sit across xGMI), drains, meets, writes the slot's flag
 // = this waypoint's epoch; then waits for the world's flags in its OWN buffer and adds the slots in
 // rank order -- every rank the same sum, bit for bit, whatever the arrival order.  Slots alternate
-// with the waypoint's parity: a rank can only be one exchange ahead of another.  The wait is bounded
+// with the parity of a running count of exchanges that is the same on every rank (calls x W + waypoint,
+// pocs_xchg_dev::parity -- NOT the waypoint's own parity: with an odd W the last exchange of a call and
+// the first of the next would share a slot): a rank can only be one exchange ahead of another.  The wait is bounded
 // (30 s, once per call: later exchanges of a call that has given up return at once): on expiry the
 // call's give-up word is set and the host reports POCS_E_DEVICE.
 // ---------------------------------------------------------------------------------------------
@@ -391,7 +361,7 @@ __device__ __forceinline__ unsigned long long* xchg_flag(double* buf, int parity
 // -> a.moments[w][r] and l_mom (LDS; may be `mine`).  s_ok: one int of LDS.  false = gave up.
 __device__ __forceinline__ bool gmm_exchange_rows(const pocs_gmm_launch& a, const pocs_xchg_dev& x, const int K, const int w, const int r,
                                                   const double* mine, double* l_mom, const int tid, const int nthreads, int* s_ok) {
-  const int NC = K * POCS_NMOM, parity = w & 1;
+  const int NC = K * POCS_NMOM, parity = x.parity;
   for (int i = tid; i < NC * x.world; i += nthreads) {
     const int q = i / NC, c = i - q * NC;
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(xchg_row(x.buf[q], parity, x.rank, r) + c),
@@ -450,53 +420,88 @@ __global__ __launch_bounds__(128) void k_gmm_exchange(pocs_gmm_launch a, pocs_xc
   if (w + 1 < a.W) advance_block(a, K, w + 1, r, s_adv, s_spec, true, tid, 128);     // starts with a barrier after staging
 }
 
-// A wave leaves component `k`: its 16-lane row sums of (nFree, 9 sums) are ADDED to the task's LDS
-// rows of that component -- every 16-lane row of threads owns one row of sums, a wave meets a component
-// once per task, the add only matters for a component it never touched (+ 0) -- and the thread-private
-// sums restart.  Column 1 of a row (nColl) stays 0: the collisions of a component are what is left of
-// its block of samples (gmm_close_sums).
-template <int NC>
-__device__ __forceinline__ void flush_component(double (*s_red)[NC], int k, double (&acc)[10], int tid) {
-  const int row = tid >> 4;
-  const bool writer = (tid & 15) == 0;
-  double* dst = &s_red[row][k * POCS_NMOM];
+// ---------------------------------------------------------------------------------------------
+// The moment sums have ONE fixed shape, whatever the launch looks like ("summation
+// tree"; oracle/pocs_oracle.c restates it and the two agree bit for bit):
+//   lane chain   a lane's samples of one component inside one UNIT-WAVE -- wave v (tid / 64) of virtual slice
+//                j of the run, over the slice's chunks in order, sample 2 lp before 2 lp + 1 -- accumulated
+//                sequentially: sums += x, fma(x, x, sum) ...; survivors counted as integers;
+//   wave sum     the 64 lane chains: eight runs of eight lanes added in lane order, then
+//                ((g0 + g1) + (g2 + g3)) + ((g4 + g5) + (g6 + g7))                         (flush_unit)
+//   row          of (virtual slice, component): the eight wave sums in wave order          (gmm_emit_rows)
+//   total        the run's VS rows as sixteen interleaved partial sums, then those in order (gmm_close_sums)
+// A run always has the same VS virtual slices (a function of the shard's sample count only), so the
+// result does not depend on how many runs share a launch, on the blocks a launch uses, or on which
+// block or wave worked on which slice: a batch of R runs, run-ahead and R single calls give the same bits.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double oct_sum(double s) {     // lanes 8 j .. 8 j + 7 hold g0 .. g7 -> all hold the sum above
+  s += dpp_f64<0xB1>(s);     // quad_perm [1,0,3,2]
+  s += dpp_f64<0x4E>(s);     // quad_perm [2,3,0,1]
+  s += dpp_f64<0x141>(s);    // row_half_mirror
+  return s;
+}
+
+// A wave leaves component `k` of the unit it is working on (held virtual slice `tl`, run buffer `rb`): its
+// lane chains -> the wave sum -> LDS (slot[tl][wave] if this is the unit's first component, otherwise the
+// wave's xtra entry of k), and the chains restart.  By LDS transposition, five then four sums at a
+// time: every lane writes its values, lane 8 j + q adds lanes 8 q .. 8 q + 7 of sum j, oct_sum adds the
+// eight q.  One wave: the LDS executes a wave's instructions in order, nothing else synchronises.
+template <int K, int TB>
+__device__ __forceinline__ void flush_unit(gmm_smem<K, TB>& sm, const int wave, const int lane, const int rb, const int tl,
+                                           const int k, bool& first, double (&acc)[9], int& nfree) {
+  double* const T = &sm.tr[wave][0][0];
+  double* const dst = first ? &sm.slot[tl][wave][0] : &sm.xtra[rb][wave][k][0];
+  const int j = lane >> 3, q = lane & 7;
 #pragma unroll
-  for (int j = 0; j < 10; ++j) {
-    const double v = row_sum(acc[j]);
-    if (writer) dst[j == 0 ? 0 : 1 + j] += v;
-    acc[j] = 0.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int nv = pass == 0 ? 5 : 4, v0 = pass == 0 ? 0 : 5;
+#pragma unroll
+    for (int i = 0; i < nv; ++i) T[i * POCS_FLUSH_PITCH + lane] = acc[v0 + i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double s = 0.0;
+    if (j < nv) {
+      const double* p = &T[j * POCS_FLUSH_PITCH + 8 * q];
+      s = p[0]; s += p[1]; s += p[2]; s += p[3]; s += p[4]; s += p[5]; s += p[6]; s += p[7];
+    }
+    s = oct_sum(s);
+    if (j < nv && q == 0) dst[1 + v0 + j] = s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+  if (lane == 0) {
+    dst[0] = (double)nfree;
+    if (first) sm.kf[tl][wave] = k; else sm.xj[rb][wave][k] = tl;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc[i] = 0.0;
+  nfree = 0;
+  first = false;
 }
 
-// Once per block: the log / sector tables and the obstacle table -> LDS.
-template <int K, int TB, int NB>
-__device__ __forceinline__ void gmm_stage_static(const pocs_gmm_launch& a, gmm_smem<K, TB, NB>& sm) {
-  stage_tables(a.tables, &sm.tab);
-  for (int j = threadIdx.x; j < a.M * POCS_OBS_STRIDE; j += TB) sm.obs[j] = a.env->obs[j];
-}
-
-// Cull the obstacle table against the bounding box of the mixture staged in par[buf] (ONE wave, all 64
+// Cull the obstacle table against the bounding box of the mixture staged in par[rb] (ONE wave, all 64
 // lanes).  A Box-Muller normal is bounded: u >= 2^-32 gives |z| <= sqrt(64 ln 2) < 6.661
-// (pocs_normal_pair_w2; 6.67 leaves 0.1 % for the rounding of radius * cos), so every pose the task can
+// (pocs_normal_pair_w2; 6.67 leaves 0.1 % for the rounding of radius * cos), so every pose the run can
 // draw lies within mean_k +- 6.67 (|L00|, |L10|+|L11|) of some component; an obstacle whose inflated
 // box (the broad phase of pocs_box_hit) misses that region is rejected by the broad phase for every
 // sample, so dropping it here changes no flag.
 //
 // The same bound on the heading makes the broad phase of the kept records tighter than the table's: the
-// table inflates an obstacle's box by the footprint's bounding RADIUS (any heading); a task whose
+// table inflates an obstacle's box by the footprint's bounding RADIUS (any heading); a run whose
 // headings all lie in [t_lo, t_hi] needs only the footprint's largest half-extent along world x and
 // along world y over that range (two convex sets that touch overlap in every projection).  Where the
 // robot's heading is known to a fraction of a radian -- most of a plan -- far fewer poses reach the
 // narrow phase, and none that could touch is lost: the flags do not change.
 //   (pocs_footprint_extent, pocs_collide.h: host + device, checked on the CPU against a dense scan)
-template <int K, int TB, int NB>
-__device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, TB, NB>& sm, const int buf, const int lane) {
+template <int K, int TB>
+__device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm, const int rb, const int lane) {
   const pocs_footprint fp = a.fp;
   const int M = a.M;
+  const double* const obs = sm.obs();
   double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300, tlo = 1e300, thi = -1e300;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const double* p = &sm.par[buf][k * POCS_PARAM_STRIDE];
+    const double* p = &sm.par[rb][k * POCS_PARAM_STRIDE];
     const double ex = 6.67 * fabs(p[3]), ey = 6.67 * (fabs(p[4]) + fabs(p[5])), et = 6.67 * (fabs(p[6]) + fabs(p[7]) + fabs(p[8]));
     xlo = fmin(xlo, p[0] - ex); xhi = fmax(xhi, p[0] + ex);
     ylo = fmin(ylo, p[1] - ey); yhi = fmax(yhi, p[1] + ey);
@@ -511,8 +516,8 @@ __device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, T
   bool keep = false;
   double bx = 0.0, by = 0.0;
   if (lane < M) {
-    const double* o = &sm.obs[lane * POCS_OBS_STRIDE];
-    // the obstacle's own world box (as pocs_prepare_obstacle) + the footprint's extents for this task
+    const double* o = &obs[lane * POCS_OBS_STRIDE];
+    // the obstacle's own world box (as pocs_prepare_obstacle) + the footprint's extents for this run
     bx = fmin(o[6], fma(o[4], fabs(o[2]), o[5] * fabs(o[3])) * (1.0 + 1e-12) + ext_x);
     by = fmin(o[7], fma(o[4], fabs(o[3]), o[5] * fabs(o[2])) * (1.0 + 1e-12) + ext_y);
     keep = !(o[0] - bx > xhi || o[0] + bx < xlo || o[1] - by > yhi || o[1] + by < ylo);
@@ -521,85 +526,69 @@ __device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, T
   if (keep) {
     const int pos = __popcll(mask & ((1ull << lane) - 1ull));
 #pragma unroll
-    for (int j = 0; j < 6; ++j) sm.keep[buf][pos * POCS_OBS_STRIDE + j] = sm.obs[lane * POCS_OBS_STRIDE + j];
-    sm.keep[buf][pos * POCS_OBS_STRIDE + 6] = bx;
-    sm.keep[buf][pos * POCS_OBS_STRIDE + 7] = by;
+    for (int j = 0; j < 6; ++j) sm.keep[rb][pos * POCS_OBS_STRIDE + j] = obs[lane * POCS_OBS_STRIDE + j];
+    sm.keep[rb][pos * POCS_OBS_STRIDE + 6] = bx;
+    sm.keep[rb][pos * POCS_OBS_STRIDE + 7] = by;
   }
-  if (lane == 0) sm.nkeep[buf] = __popcll(mask);
+  if (lane == 0) sm.nkeep[rb] = __popcll(mask);
 }
 
 // ---------------------------------------------------------------------------------------------
-// THE BODY of a task = slice `slot` (of a.slices) of run r at waypoint w, as every thread of the block
-// runs it: GM_Model::sampleNPoints (GM_Model.h:83-116) + checkMatrixCollisions (MCSimulator.h:241-253)
-// + the moment sums (:592-611), fused, one PAIR of samples per thread and iteration; ends with the
-// thread's sums folded into the task's LDS rows (each 16-lane row of threads owns one row: no
-// barrier in here).  s_par / s_keep / nkeep: the task's staged parameters and culled obstacle table.
-// WT: write-through sample stores (k_gmm_run).  What a thread computes depends on (r, w, slot,
-// a.slices, a.chunks, its tid) only -- not on the kernel, the block, or when: k_gmm_step and
-// k_gmm_run produce bitwise the same rows.  seed = the run's; [c_begin, c_end) = the slice's chunks
-// (gmm_slice_chunks), both wave-uniform.
+// THE BODY: units [ta, tb) of the launch (unit t = virtual slice t mod VS of run t / VS; at most
+// POCS_GMM_SUB of them, of at most two runs r0 and r0 + 1 whose parameters and culled tables are staged
+// in buffers 0 and 1), as every thread of the block runs them: GM_Model::sampleNPoints
+// (GM_Model.h:83-116) + checkMatrixCollisions (MCSimulator.h:241-253) + the moment sums (:592-611),
+// fused, one PAIR of samples per thread and iteration.  The waves of the block do not meet in here: each
+// works through the units at its own pace and leaves its wave sums in LDS (flush_unit).  What a lane adds
+// up, and in which order, depends on (run, virtual slice, wave, lane) only.
 // ---------------------------------------------------------------------------------------------
-template <int K, bool STORE, bool WT, int TB>
-__device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_tables* s_tab, const double* s_par,
-                                         const double* s_keep, const int nkeep, double (*s_red)[K * POCS_NMOM],
-                                         const int w, const int r, uint64_t seed, const long long c_begin, const long long c_end
-#if defined(POCS_TASK_STAMPS)
-                                         , unsigned long long (&st_)[12], unsigned long long& last_
-#endif
-                                         ) {
-  constexpr int NC = K * POCS_NMOM;
-  const int tid = threadIdx.x;
+template <int K, bool STORE, int TB>
+__device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm, const int w, const int r0,
+                                          const int ta, const int tb) {
+  const pocs_tables* const s_tab = &sm.tab;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const pocs_footprint fp = a.fp;
-  seed = (uint64_t)uniform64((long long)seed);       // scalar registers, provably
-  // Samples come in component blocks and a thread's sample indices only grow, so a wave works
-  // through the components in order: ONE set of sums per thread (the wave's current component),
-  // folded into the task's LDS rows when the wave moves on to the next component.
-  //   acc[0] = survivors, acc[1..9] = sums of x, y, t, xx, xy, xt, yy, yt, tt over them
-  double acc[10];
-  int kcur = 0;                                      // wave-uniform
+  const int vs_mask = (1 << a.vs_shift) - 1;
+  //   acc[0..8] = sums of x, y, t, xx, xy, xt, yy, yt, tt over the survivors of the component being
+  //   accumulated (a wave works through the component blocks in order), nfree = their number (the wave's)
+  double acc[9];
+  int nfree = 0;
 #pragma unroll
-  for (int j = 0; j < 10; ++j) acc[j] = 0.0;
-  for (int c = tid & 15; c < NC; c += 16) s_red[tid >> 4][c] = 0.0;      // this row of threads' own row of sums
-
-  // a.first is even (checked by the host), so local sample 2*lp is global sample first + 2*lp.
-  const long long npairs = (a.count + 1) >> 1;
+  for (int j = 0; j < 9; ++j) acc[j] = 0.0;
+  // Positions inside the shard are 32-bit (the host refuses shards of 2^31 samples and more): LOCAL sample
+  // i is global sample first + i, local pair lp holds local samples 2 lp, 2 lp + 1 (a.first is even,
+  // checked by the host), and everything the unit loop decides -- chunk ranges, the end of a component
+  // block, whole or general iteration -- is scalar integer arithmetic.
+  const int count = (int)a.count;
+  const int npairs = (count + 1) >> 1;
   const uint64_t pair0 = (uint64_t)(a.first >> 1);
   const double first_d = (double)a.first;
-  double cumn[K > 1 ? K - 1 : 1];                   // cumulative component counts (wave-uniform)
-#pragma unroll
-  for (int j = 0; j < K - 1; ++j) cumn[j] = s_par[j * POCS_PARAM_STRIDE + 9];
-  // (Keeping the wave's component parameters in scalar registers instead of reading them at one LDS
-  // address spills scalar registers: measured 5 % slower at K = 3.)
-  const long long wave_first = 2 * (long long)(__builtin_amdgcn_readfirstlane(tid >> 6) * 64);
-  const long long g_end = a.first + a.count;
-  long long seg_end = 0;
-  int kw = 0;
-  // The loop counter is wave-uniform (SGPRs) and the lane adds its tid: the store addresses are a
-  // scalar base per iteration plus a constant 16*tid, no per-lane 64-bit address arithmetic.
-  double* const xr = a.x + (size_t)r * a.sample_stride;          // this run's slice (sample_stride is even)
-  double* const yr = a.y + (size_t)r * a.sample_stride;
-  double* const tr = a.th + (size_t)r * a.sample_stride;
-  int16_t* const fr = a.flags + (size_t)r * a.sample_stride;
+  const int wave_first = 128 * wave;                // the wave's first sample within a chunk
 #if !defined(POCS_NO_PRIO_ROTATION)
   // The (up to) four waves of a SIMD -- two of this block, two of the co-resident one -- are arbitrated
   // by priority, then AGE: left alone, the oldest wave of a SIMD runs ~1.7 x faster than the youngest for
   // the whole launch.  Rotating the priority with the iteration gives every wave the same share.
   // slot = which of the block's waves on this SIMD: wave v runs on SIMD v mod 4, so waves v and v + 4 share
-  // one (HW_ID stamps of a diagnostic build, tools/step_stamps.sh).  The second block of a CU is (observed,
-  // speed only) the one dispatched 256 blocks later.  What the rotation does NOT achieve (same stamps): the
-  // older of a SIMD's waves still win -- a block's waves 4-7 end 3 % after its waves 0-3, the blocks
-  // dispatched second 19 % after the first.  Rotating by the wall clock instead of the iteration count (equal
-  // TIME at each level, no two waves of a SIMD ever tied) measured worse at 2.5 and 5 us per level, +0.8 % at 10.
-  const int prio_slot = (TB >= 512 ? __builtin_amdgcn_readfirstlane((tid >> 6) >> 2) : 0) +
-                        (TB >= 512 ? 2 : 1) * (int)(((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 3u);
+  // one.  The second block of a CU is (observed, speed only) the one dispatched 256 blocks later.
+  const int prio_slot = (TB >= 512 ? (wave >> 2) : 0) + (TB >= 512 ? 2 : 1) * (int)((blockIdx.x >> 8) & 3u);
   int prio_it = prio_slot;
 #endif
-  POCS_STAMP(2);
+  // per run (wave-uniform; reloaded when the block's range crosses into its second run)
+  int rb = -1, nkeep = 0, kcur = 0, kw = 0;
+  const double* s_par = nullptr;
+  const double* s_keep = nullptr;
+  uint64_t seed = 0;
+  double cumn[K > 1 ? K - 1 : 1];                   // cumulative component counts
+  double *xr = nullptr, *yr = nullptr, *tr = nullptr;
+  int16_t* fr = nullptr;
+  int seg_end = 0;                                  // local sample index up to which (exclusive) the samples belong to component kw and exist
+
   // ONE iteration = 2 * TB samples, one pair per thread.  WHOLE (compile time): the wave's 128 samples lie
   // inside component block kw and inside the shard -- every lane live, both samples of its pair exist,
   // the component is the scalar kw == kcur.  Otherwise: the general case (a block boundary inside the
   // wave, the shard's last chunk), every decision per lane.  Same arithmetic per sample either way.
-  auto iteration = [&](auto whole_tag, const long long base) __attribute__((always_inline)) {
+  auto iteration = [&](auto whole_tag, const int base, const int tl, bool& first) __attribute__((always_inline)) {
     constexpr bool WHOLE = decltype(whole_tag)::value;
 #if !defined(POCS_NO_PRIO_ROTATION)
     switch (prio_it++ & 3) {                       // s_setprio takes an immediate
@@ -609,8 +598,8 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
       default: __builtin_amdgcn_s_setprio(3); break;
     }
 #endif
-    const long long lp = base + tid;
-    const bool live = WHOLE || lp < npairs;        // a lane past the end computes, masked: the row sums below need every lane
+    const int lp = base + tid;
+    const bool live = WHOLE || lp < npairs;        // a lane past the end computes, masked
     double zz[2][3];
     uint32_t spare[2];
 #if defined(POCS_ABLATE_RNG)          // timing-only builds (tools/ablate.sh): outputs are wrong
@@ -634,10 +623,10 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(seed_it));
 #endif
-    pocs_normal3_pair(seed_it, pair0 + (uint64_t)lp, (uint32_t)w, POCS_STREAM_GMM, s_tab, zz[0], zz[1], &spare[0], &spare[1]);
+    pocs_normal3_pair(seed_it, pair0 + (uint64_t)(unsigned)lp, (uint32_t)w, POCS_STREAM_GMM, s_tab, zz[0], zz[1], &spare[0], &spare[1]);
 #endif
-    const long long i0 = 2 * lp;
-    const bool two = WHOLE || (live && (i0 + 1) < a.count);  // false only for the last sample of an odd shard
+    const int i0 = 2 * lp;
+    const bool two = WHOLE || (live && (i0 + 1) < count);  // false only for the last sample of an odd shard
     double xs[2], ys[2], ts[2];
     bool hits[2];
     int ks[2];
@@ -665,26 +654,26 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
 #endif
     }
 #if defined(POCS_ABLATE_MOMENTS)
-    acc[1] += xs[0] + ys[0] + ts[0] + xs[1]; acc[0] += (hits[0] || (two && ks[1] == 0)) ? 0.0 : 1.0;
+    acc[1] += xs[0] + ys[0] + ts[0] + xs[1]; nfree += (hits[0] || (two && ks[1] == 0)) ? 0 : 1;
 #else
     // T1 sums over the collision-free samples of the component being accumulated:
-    //   acc += (1, x, y, t, x x, x y, x t, y y, y t, t t)      (the products inside the fma).
+    //   (x, y, t, x x, x y, x t, y y, y t, t t) with the products inside the fma; survivors by population count.
     if (WHOLE) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+        nfree += __popcll(__ballot(!hits[h]));
         if (!hits[h]) {                             // the few lanes that collided sit this out
           const double x = xs[h], y = ys[h], t = ts[h];
-          acc[0] += 1.0;
-          acc[1] += x; acc[2] += y; acc[3] += t;
-          acc[4] = fma(x, x, acc[4]); acc[5] = fma(x, y, acc[5]); acc[6] = fma(x, t, acc[6]);
-          acc[7] = fma(y, y, acc[7]); acc[8] = fma(y, t, acc[8]); acc[9] = fma(t, t, acc[9]);
+          acc[0] += x; acc[1] += y; acc[2] += t;
+          acc[3] = fma(x, x, acc[3]); acc[4] = fma(x, y, acc[4]); acc[5] = fma(x, t, acc[5]);
+          acc[6] = fma(y, y, acc[6]); acc[7] = fma(y, t, acc[7]); acc[8] = fma(t, t, acc[8]);
         }
       }
     } else {
       // The components present in the wave are visited in increasing order (scalar loop), the previous
-      // component's sums being flushed to the LDS rows first; with ind = 1.0 for a surviving sample of the
-      // component and 0.0 otherwise, (xm, ym, tm) = ind * (x, y, t) enter the sums -- a sample that does not
-      // count adds +-0 to every one of them, which is why the WHOLE form above gives the same bits.
+      // component's chains being flushed first; with ind = 1.0 for a surviving sample of the component and
+      // 0.0 otherwise, (xm, ym, tm) = ind * (x, y, t) enter the sums -- a sample that does not count adds +-0
+      // to every one of them, which is why the WHOLE form above gives the same bits.
       // Sample indices grow with the lane: the wave's first LIVE lane holds its first component, lane 63 its last.
       const unsigned long long live_mask = __ballot(live);
       const int klo = live_mask ? __builtin_amdgcn_readlane(ks[0], (int)__builtin_ctzll(live_mask)) : K;
@@ -692,16 +681,17 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
         if (kk < klo || kk > khi) continue;                                 // scalar compares
-        if (kk != kcur) { flush_component<NC>(s_red, kcur, acc, tid); kcur = kk; }
+        if (kk != kcur) { flush_unit(sm, wave, lane, rb, tl, kcur, first, acc, nfree); kcur = kk; }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const bool sel = (h == 0 ? live : two) && ks[h] == kk;
-          const double ind = (sel && !hits[h]) ? 1.0 : 0.0;
+          const bool cnt = sel && !hits[h];
+          nfree += __popcll(__ballot(cnt));
+          const double ind = cnt ? 1.0 : 0.0;
           const double xm = ind * xs[h], ym = ind * ys[h], tm = ind * ts[h];
-          acc[0] += ind;
-          acc[1] += xm; acc[2] += ym; acc[3] += tm;
-          acc[4] = fma(xm, xs[h], acc[4]); acc[5] = fma(xm, ys[h], acc[5]); acc[6] = fma(xm, ts[h], acc[6]);
-          acc[7] = fma(ym, ys[h], acc[7]); acc[8] = fma(ym, ts[h], acc[8]); acc[9] = fma(tm, ts[h], acc[9]);
+          acc[0] += xm; acc[1] += ym; acc[2] += tm;
+          acc[3] = fma(xm, xs[h], acc[3]); acc[4] = fma(xm, ys[h], acc[4]); acc[5] = fma(xm, ts[h], acc[5]);
+          acc[6] = fma(ym, ys[h], acc[6]); acc[7] = fma(ym, ts[h], acc[7]); acc[8] = fma(tm, ts[h], acc[8]);
         }
       }
     }
@@ -709,117 +699,146 @@ __device__ __forceinline__ void gmm_body(const pocs_gmm_launch& a, const pocs_ta
     if (STORE && live) {
       // Both poses of the pair leave together.  For the last sample of an odd shard the second slot is
       // the pair's unused twin: it lands in the padding element of the run's slice (sample_stride >=
-      // count + 1 then) and is never read back.  Written once, never re-read by the kernels.
-      // (Issuing the three pose stores BEFORE the footprint test, so that they drain under it, was
-      // measured equal: r02, 507 vs 496 us per 64-run launch.)
-      const size_t ub = 2 * (size_t)base;
+      // count + 1 then) and is never read back.  Written once, never re-read by the kernels: non-temporal,
+      // past the caches.  The loop counter is wave-uniform (SGPRs) and the lane adds its tid: the store
+      // addresses are a scalar base per iteration plus a constant 16*tid, no per-lane 64-bit arithmetic.
+      const size_t ub = 2 * (size_t)(unsigned)base;
       const int fl = (hits[0] ? 1 : 0) | ((two && hits[1]) ? 0x10000 : 0);
-      if (WT) {                                    // k_gmm_run: write-through, see store16_wt
-        store16_wt(xr + ub, 16u * (unsigned)tid, (v2d){xs[0], xs[1]});
-        store16_wt(yr + ub, 16u * (unsigned)tid, (v2d){ys[0], ys[1]});
-        store16_wt(tr + ub, 16u * (unsigned)tid, (v2d){ts[0], ts[1]});
-        store4_wt(fr + ub, 4u * (unsigned)tid, fl);
-      } else {                                     // a launch per waypoint: non-temporal, past the caches
-        store16_nt(xr + ub, 16u * (unsigned)tid, (v2d){xs[0], xs[1]});
-        store16_nt(yr + ub, 16u * (unsigned)tid, (v2d){ys[0], ys[1]});
-        store16_nt(tr + ub, 16u * (unsigned)tid, (v2d){ts[0], ts[1]});
-        store4_nt(fr + ub, 4u * (unsigned)tid, fl);
-      }
+      store16_nt(xr + ub, 16u * (unsigned)tid, (v2d){xs[0], xs[1]});
+      store16_nt(yr + ub, 16u * (unsigned)tid, (v2d){ys[0], ys[1]});
+      store16_nt(tr + ub, 16u * (unsigned)tid, (v2d){ts[0], ts[1]});
+      store4_nt(fr + ub, 4u * (unsigned)tid, fl);
     }
   };
-  // A wave's 128 samples of an iteration nearly always lie inside ONE component block and inside the shard:
-  // those iterations run in the inner loop below, which knows nothing of the general case (no per-lane
-  // index compares, no masks, no flush; the accumulators stay where they are).  The wave's position is
-  // looked up again (scalar) whenever the next iteration is not of that kind.
-  //   seg_end = global index up to which (exclusive) whole waves belong to component kw and exist
-  const long long end = c_end * TB;
-  for (long long base = c_begin * TB; base < end;) {
-    long long g0 = a.first + 2 * base + wave_first;                         // global index of the wave's first sample
-    {
-      int kk = 0;
+
+  // the component block the wave's local sample l0 lies in, and where whole waves of it end
+  auto lookup = [&](const int l0) __attribute__((always_inline)) {
+    const double g0 = first_d + (double)l0;
+    int kk = 0;
 #pragma unroll
-      for (int j = 0; j < K - 1; ++j) kk += (cumn[j] <= (double)g0) ? 1 : 0;
-      kw = __builtin_amdgcn_readfirstlane(kk);
-      const long long blk_end = kw < K - 1 ? (long long)s_par[kw * POCS_PARAM_STRIDE + 9] : g_end;
-      seg_end = uniform64(blk_end < g_end ? blk_end : g_end);
+    for (int q = 0; q < K - 1; ++q) kk += (cumn[q] <= g0) ? 1 : 0;
+    kw = __builtin_amdgcn_readfirstlane(kk);
+    double e = (double)count;
+    if (kw < K - 1) e = fmin(e, s_par[kw * POCS_PARAM_STRIDE + 9] - first_d);      // exact: integers below 2^53
+    seg_end = __builtin_amdgcn_readfirstlane((int)e);
+  };
+  for (int t = ta; t < tb; ++t) {
+    const int tl = t - ta;
+    const int r = t >> a.vs_shift, j = t & vs_mask;
+    if (r - r0 != rb) {                              // (scalar) the block's first unit, or its range enters run r0 + 1
+      rb = r - r0;
+      s_par = sm.par[rb]; s_keep = sm.keep[rb];
+      nkeep = __builtin_amdgcn_readfirstlane(sm.nkeep[rb]);
+      seed = (uint64_t)uniform64((long long)sm.seed[rb]);         // scalar registers, provably
+#pragma unroll
+      for (int q = 0; q < K - 1; ++q) cumn[q] = s_par[q * POCS_PARAM_STRIDE + 9];
+      // (Keeping the wave's component parameters in scalar registers instead of reading them at one LDS
+      // address spills scalar registers: measured 5 % slower at K = 3.)
+      xr = a.x + (size_t)r * a.sample_stride;          // this run's slice (sample_stride is even)
+      yr = a.y + (size_t)r * a.sample_stride;
+      tr = a.th + (size_t)r * a.sample_stride;
+      fr = a.flags + (size_t)r * a.sample_stride;
+      seg_end = 0;                                     // nothing known about this run's component blocks yet
     }
-    if (g0 + 128 <= seg_end) {
-      if (kw != kcur) { flush_component<NC>(s_red, kcur, acc, tid); kcur = kw; }
-      do {
-        iteration(std::true_type{}, base);
+    // chunks [c_begin, c_end) of virtual slice j: a fixed cut of the run's chunks into VS = 2^vs_shift ranges
+    const int c_begin = (int)(((long long)j * a.chunks) >> a.vs_shift);
+    const int c_end = (int)(((long long)(j + 1) * a.chunks) >> a.vs_shift);
+    bool first = true;                               // (scalar) nothing of this unit has been flushed yet
+    // A wave's samples only move forward within a run, so the component block found for an earlier unit still
+    // holds while the wave's 128 samples end before seg_end; it is looked up again (a few vector compares)
+    // only when they do not: at a block boundary, at the shard's end.
+    const int end = c_end * TB;
+    int base = c_begin * TB;
+    if (2 * base + wave_first + 128 > seg_end) lookup(2 * base + wave_first);
+    kcur = kw;                                       // the component the wave's first sample of the unit belongs to
+    // A wave's 128 samples of an iteration nearly always lie inside ONE component block and inside the shard:
+    // those iterations run in the inner loop below, which knows nothing of the general case (no per-lane
+    // index compares, no masks, no flush; the accumulators stay where they are).
+    while (base < end) {
+      int l0 = 2 * base + wave_first;                                        // local index of the wave's first sample
+      if (l0 + 128 > seg_end) lookup(l0);
+      if (l0 + 128 <= seg_end) {
+        if (kw != kcur) { flush_unit(sm, wave, lane, rb, tl, kcur, first, acc, nfree); kcur = kw; }
+        do {
+          iteration(std::true_type{}, base, tl, first);
+          base += TB;
+          l0 += 2 * TB;
+        } while (base < end && l0 + 128 <= seg_end);
+      } else {
+        iteration(std::false_type{}, base, tl, first);
         base += TB;
-        g0 += 2 * TB;
-      } while (base < end && g0 + 128 <= seg_end);
-    } else {
-      iteration(std::false_type{}, base);
-      base += TB;
+      }
     }
-  }
 #if !defined(POCS_NO_PRIO_ROTATION)
-  // Everything between two bodies -- flush, drain, closing a task, adding a run's rows, advancing its
-  // mixture, staging the next task -- is short and other waves (or blocks) wait for it: it runs at the
-  // TOP priority, or the sampling waves of the same SIMD (priority 0..3 in turn) leave it the crumbs.
-  __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);                   // flushes run at the top priority: other waves will wait for them
 #endif
-  POCS_STAMP(3);
-  flush_component<NC>(s_red, kcur, acc, tid);       // the last component's sums -> the LDS rows
-  POCS_STAMP(4);
+    flush_unit(sm, wave, lane, rb, tl, kcur, first, acc, nfree);      // the unit's last component
+  }
 }
 
-// chunks [begin, end) of slice `slot`
-__device__ __forceinline__ void gmm_slice_chunks(const pocs_gmm_launch& a, const int slot, long long* begin, long long* end) {
-  *begin = ((long long)slot * a.chunks) / a.slices;
-  *end = ((long long)(slot + 1) * a.chunks) / a.slices;
+// The rows of the held units [ta, tb): column c of (virtual slice, component) = the eight wave sums in wave
+// order -- whichever of them the unit has: slot if the component was the wave's first there, xtra if it
+// started inside the wave's share, +0 otherwise -- stored write-through to the run's partial rows.
+// Column 1 (collisions) stays 0: a component's collisions are what is left of its block (gmm_close_sums).
+template <int K, int TB>
+__device__ __forceinline__ void gmm_emit_rows(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm, const int r0, const int ta, const int tb) {
+  constexpr int NC = K * POCS_NMOM, NW = TB / 64;
+  for (int i = threadIdx.x; i < (tb - ta) * NC; i += TB) {
+    const int tl = i / NC, c = i - tl * NC, k = c / POCS_NMOM, col = c - k * POCS_NMOM;
+    const int rb = ((ta + tl) >> a.vs_shift) - r0;
+    double v = 0.0;
+    if (col != 1) {
+      const int s = col == 0 ? 0 : col - 1;
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        double p = 0.0;
+        if (sm.kf[tl][u] == k) p = sm.slot[tl][u][s];
+        else if (sm.xj[rb][u][k] == tl) p = sm.xtra[rb][u][k][s];
+        v = (u == 0) ? p : v + p;
+      }
+    }
+    store_wt(&a.partial[(size_t)(ta + tl) * NC + c], v);        // [run][VS][NC] = [unit][NC]
+  }
 }
 
-// Column c of the task's partial row: the RB rows of sums added in row order.
-template <int NC, int RB>
-__device__ __forceinline__ double gmm_row_total(const double (*s_red)[NC], const int c) {
-  double v = s_red[0][c];
-#pragma unroll 8
-  for (int q = 1; q < RB; ++q) v += s_red[q][c];
-  return v;
-}
-
-// The closer of (r, w) -- the block (k_gmm_step) or wave (k_gmm_run) that drew the run's last ticket,
-// behind its acquire -- adds the a.slices partial rows of the run in a FIXED order that does not depend
-// on who adds them: sixteen interleaved partial sums per column, P_g = row g + row (g + 16) + row (g + 32)
-// + ... in that order, then P_0 + P_1 + ... + P_15 in that order.  (Up to 16 slices -- 32 runs per
-// launch and more -- that is plain slice order.)  Every (g, column) is one work item: its loads are
-// L1-bypassing and independent, so the `nthreads` threads have the whole table in flight at once --
-// ONE memory round trip instead of one per 32 rows, which is what a lone run's 256 slices used to
-// cost (7 us of a 31 us launch).  `stage`: >= 16 * NC doubles of LDS.  `sync` = the barrier of those
-// threads.  The collisions of a component are what is left of its block of this shard's samples:
-// nColl_k = n_k - nFree_k, with [cum_{k-1}, cum_k) the component's global sample range (par[k][9],
-// cum_{K-1} = n_total).  Result: tot[c], and moments[w][r][c] in global memory (it leaves the launch at
-// the kernel boundary).
-template <int K, int RB, typename Sync>
+// The closer of (r, w) -- the block that drew the run's last ticket, behind its acquire -- adds the VS
+// partial rows of the run in a FIXED order that does not depend on who adds them: sixteen interleaved
+// partial sums per column, P_g = row g + row (g + 16) + row (g + 32) + ... in that order, then
+// P_0 + P_1 + ... + P_15 in that order.  Every (g, column) is one work item: its loads are L1-bypassing
+// and independent, so the block has the whole table in flight at once -- ONE memory round trip.
+// `stage`: >= 16 * NC doubles of LDS.  The collisions of a component are what is left of its block of
+// this shard's samples: nColl_k = n_k - nFree_k, with [cum_{k-1}, cum_k) the component's global sample
+// range (par[k][9], cum_{K-1} = n_total).  Result: tot[c], and moments[w][r][c] in global memory (it
+// leaves the launch at the kernel boundary).
+template <int K>
 __device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const int w, const int r, const double* s_par,
-                                               double* stage, double* tot, const int tid, const int nthreads, Sync sync) {
+                                               double* stage, double* tot, const int tid, const int nthreads) {
   constexpr int NC = K * POCS_NMOM, G = 16;
-  static_assert(RB >= G, "the staging rows hold the sixteen partial sums");
-  const int S = a.slices;
+  const int S = 1 << a.vs_shift;
   const double* src = a.partial + (size_t)r * S * NC;
   for (int i = tid; i < G * NC; i += nthreads) {
     const int g = i / NC, c = i - g * NC;
-    double v = 0.0;
-    int q = g;
-    for (; q + 3 * G < S; q += 4 * G) {              // four rows of the item in flight at a time, added in row order
-      const double v0 = load_wt(&src[(size_t)q * NC + c]), v1 = load_wt(&src[(size_t)(q + G) * NC + c]);
-      const double v2 = load_wt(&src[(size_t)(q + 2 * G) * NC + c]), v3 = load_wt(&src[(size_t)(q + 3 * G) * NC + c]);
-      v += v0; v += v1; v += v2; v += v3;
+    // the item's (up to) sixteen rows g, g + 16, ... are all requested before the first is waited for -- ONE
+    // memory round trip for the run's 256 rows -- and added in row order
+    double v[POCS_GMM_MAX_VS / G];
+#pragma unroll
+    for (int u = 0; u < POCS_GMM_MAX_VS / G; ++u) {
+      const int q = g + u * G;
+      v[u] = q < S ? load_wt(&src[(size_t)q * NC + c]) : 0.0;
     }
-    for (; q < S; q += G) v += load_wt(&src[(size_t)q * NC + c]);
-    stage[i] = v;
+    double t = 0.0;
+#pragma unroll
+    for (int u = 0; u < POCS_GMM_MAX_VS / G; ++u) if (g + u * G < S) t += v[u];
+    stage[i] = t;
   }
-  sync();
+  __syncthreads();
   for (int c = tid; c < NC; c += nthreads) {
     double v = stage[c];
     const int ng = S < G ? S : G;
     for (int g = 1; g < ng; ++g) v += stage[g * NC + c];
     tot[c] = v;
   }
-  sync();
+  __syncthreads();
   const double lo = (double)a.first, hi = (double)(a.first + a.count);
   for (int k = tid; k < K; k += nthreads) {
     const double c0 = (k == 0) ? 0.0 : s_par[(k - 1) * POCS_PARAM_STRIDE + 9];
@@ -827,358 +846,101 @@ __device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const i
     const double n_k = fmax(0.0, fmin(c1, hi) - fmax(c0, lo));
     tot[k * POCS_NMOM + 1] = n_k - tot[k * POCS_NMOM];
   }
-  sync();
+  __syncthreads();
   for (int c = tid; c < NC; c += nthreads) a.moments[((size_t)w * a.nruns + r) * NC + c] = tot[c];
 }
 
-// One waypoint as its own launch: grid = (slices, runs), block (j, r) = task (a.waypoint, r, j).  The
-// per-waypoint form, for a caller that exchanges the moments between waypoints (sharded over GPUs) and
-// for calls with too few runs to keep k_gmm_run's pipeline full.
-//   head  sampler parameters of (r, w) -> LDS, exact culling of the obstacle table;
-//   body  gmm_body;
-//   tail  the task's rows -> ONE write-through partial row (r, slot) -> every storing wave drains ->
-//         the block meets -> ticket (r, w); the block that draws the last one acquires, adds the
-//         run's partial rows and (one GPU) advances the mixture to the next waypoint.
+// One waypoint of runs [run_lo, run_lo + run_cnt) of the call as ONE launch (the host issues a call's runs as
+// one launch per waypoint, or as two half-batches on two streams whose launches overlap, pocs_host.hip).
+// The launch's work is the flat list of UNITS t = r * VS + j (virtual slice j of run r); block b takes the
+// b-th `upb` of them -- every block
+// the same number, whatever the number of runs, which is what lets a launch of ANY number of runs fill
+// the 512 resident blocks evenly.  A block's range may cross from one run into the next (never further:
+// upb <= VS).
+//   head  log / sector tables, the obstacle table, the sampler parameters of the block's (up to) two
+//         runs -> LDS; exact culling of the obstacle table per run (waves 0 and 1);
+//   body  gmm_units, POCS_GMM_SUB units at a time, each followed by the rows of those units -> the
+//         write-through partial rows [run][VS];
+//   tail  every storing wave drains -> the block meets -> one ticket per run it touched; the block that
+//         draws a run's last ticket acquires, adds the run's VS rows and (one GPU) advances the mixture
+//         to the next waypoint -- sharded: after exchanging the run's moments with the other ranks.
 template <int K, bool STORE, int TB>
 __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_step(pocs_gmm_launch a) {
-  typedef gmm_smem<K, TB, 1> smem_t;
-  constexpr int NC = smem_t::NC, RB = smem_t::RB;
+  typedef gmm_smem<K, TB> smem_t;
+  constexpr int NC = smem_t::NC, SUB = smem_t::SUB, NW = smem_t::NW;
   __shared__ smem_t sm;
   const int tid = threadIdx.x;
-  const int w = a.waypoint, r = blockIdx.y, slot = blockIdx.x;
-#if defined(POCS_STEP_STAMPS)
-  unsigned long long* const dbg_ = a.dbg + (((size_t)w * a.nruns + r) * a.slices + slot) * 32;
-#define POCS_STEP_STAMP(i) do { if (tid == 0) dbg_[i] = wall_clock64(); } while (0)
-#else
-#define POCS_STEP_STAMP(i) do { } while (0)
+  const int w = a.waypoint;
+  const int VS = 1 << a.vs_shift;
+  const int t_lo = a.run_lo << a.vs_shift, t_hi = (a.run_lo + a.run_cnt) << a.vs_shift;    // this launch's units
+  const int t0 = t_lo + (int)blockIdx.x * a.upb;
+  const int t1 = (t0 + a.upb < t_hi) ? t0 + a.upb : t_hi;
+  const int r0 = t0 >> a.vs_shift, r1 = (t1 - 1) >> a.vs_shift;       // the block's first and last run (r1 <= r0 + 1)
+#if defined(POCS_STAMPS)
+  unsigned long long last_ = wall_clock64();
+  if (tid == 0) atomicAdd(&g_stamps[15], 1ull);
 #endif
-  POCS_STEP_STAMP(0);
-  gmm_stage_static(a, sm);
-  for (int j = tid; j < K * POCS_PARAM_STRIDE; j += TB)
-    sm.par[0][j] = load_wt(&a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j]);
+  stage_tables(a.tables, &sm.tab);
+  for (int j = tid; j < a.M * POCS_OBS_STRIDE; j += TB) sm.obs()[j] = a.env->obs[j];
+  for (int j = tid; j < (r1 - r0 + 1) * K * POCS_PARAM_STRIDE; j += TB)   // param[r][w][..]: the two runs' records are a.W records apart
+    sm.par[j / (K * POCS_PARAM_STRIDE)][j % (K * POCS_PARAM_STRIDE)] =
+        load_wt(&a.param[((size_t)(r0 + j / (K * POCS_PARAM_STRIDE)) * a.W + w) * (K * POCS_PARAM_STRIDE) + j % (K * POCS_PARAM_STRIDE)]);
+  for (int j = tid; j < 2 * NW * K; j += TB) (&sm.xj[0][0][0])[j] = -1;
+  if (tid <= r1 - r0) sm.seed[tid] = a.hdr[r0 + tid].seed;
   __syncthreads();
   if (tid < 64) gmm_cull(a, sm, 0, tid);
-  __syncthreads();
-  long long c_begin, c_end;
-  gmm_slice_chunks(a, slot, &c_begin, &c_end);
-  c_begin = uniform64(c_begin); c_end = uniform64(c_end);      // (64-bit division runs on the vector unit)
-  POCS_STEP_STAMP(1);
-#if defined(POCS_TASK_STAMPS)
-  unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
-  gmm_body<K, STORE, false, TB>(a, &sm.tab, sm.par[0], sm.keep[0], __builtin_amdgcn_readfirstlane(sm.nkeep[0]), sm.red[0], w, r,
-                                a.hdr[r].seed, c_begin, c_end, st_, last_);
-#else
-  gmm_body<K, STORE, false, TB>(a, &sm.tab, sm.par[0], sm.keep[0], __builtin_amdgcn_readfirstlane(sm.nkeep[0]), sm.red[0], w, r,
-                                a.hdr[r].seed, c_begin, c_end);
-#endif
-  POCS_STEP_STAMP(2);
-#if defined(POCS_STEP_STAMPS)
-  if ((tid & 63) == 0) { dbg_[10 + (tid >> 6)] = wall_clock64(); dbg_[18 + (tid >> 6)] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); }
-#endif
-  __syncthreads();
-  POCS_STEP_STAMP(6);
-  if (tid < NC) store_wt(&a.partial[((size_t)r * a.slices + slot) * NC + tid], gmm_row_total<NC, RB>(sm.red[0], tid));
+  else if (tid < 128 && r1 > r0) gmm_cull(a, sm, 1, tid - 64);
+  __syncthreads();                                   // from here on the transpose scratch is the waves'
+  POCS_STAMP(0);
+  for (int ta = t0; ta < t1; ta += SUB) {
+    const int tb = (ta + SUB < t1) ? ta + SUB : t1;
+    gmm_units<K, STORE, TB>(a, sm, w, r0, ta, tb);
+    POCS_STAMP(1);
+    __syncthreads();
+    POCS_STAMP(2);
+    gmm_emit_rows(a, sm, r0, ta, tb);
+    if (tb < t1) {                                   // more units to come (only launches of > 64 runs): the slots start over
+      __syncthreads();
+      for (int j = tid; j < 2 * NW * K; j += TB) (&sm.xj[0][0][0])[j] = -1;
+      __syncthreads();
+    }
+  }
   drain_stores();
   __syncthreads();
-  POCS_STEP_STAMP(7);
-#if defined(POCS_STEP_STAMPS)
-  if (tid == 0) { dbg_[8] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); dbg_[9] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); }
-#endif
-  if (tid == 0) {
+  POCS_STAMP(3);
+  if (tid <= r1 - r0) {                              // one ticket per run touched: the blocks whose range meets [r VS, (r + 1) VS)
+    const int r = r0 + tid;
+    const int b_first = ((r << a.vs_shift) - t_lo) / a.upb, b_last_raw = ((((r + 1) << a.vs_shift) - 1) - t_lo) / a.upb;
+    const int b_last = b_last_raw < (int)gridDim.x - 1 ? b_last_raw : (int)gridDim.x - 1;
     const unsigned t = __hip_atomic_fetch_add(&a.ticket[(size_t)r * a.W + w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == (unsigned)a.slices - 1u) ? 1 : 0;
-    if (last) acquire_agent();
-    sm.last = last;
+    sm.last[tid] = (t == (unsigned)(b_last - b_first)) ? 1 : 0;
   }
+  if (tid == 0 && r1 == r0) sm.last[1] = 0;
   __syncthreads();
-  POCS_STEP_STAMP(3);
-  if (__builtin_amdgcn_readfirstlane(sm.last) == 0) return;
-  double* const l_mom = advance_ptrs(a, K, w + 1, r, sm.adv).l_mom;
-  gmm_close_sums<K, RB>(a, w, r, sm.par[0], &sm.red[0][0][0], l_mom, tid, TB, [] { __syncthreads(); });
-  POCS_STEP_STAMP(4);
-  if (a.exchange_in_tail) {
-    // sharded: the run's closer is also its messenger -- this shard's moments go to every rank, the world's
-    // come back summed in rank order, and the mixture advances here; meanwhile the other engine's sampling
-    // launch has the CUs this launch's finished blocks gave back (no launch, no host, between waypoints)
+  POCS_STAMP(4);
+#pragma nounroll
+  for (int rb = 0; rb <= r1 - r0; ++rb) {
+    if (__builtin_amdgcn_readfirstlane(sm.last[rb]) == 0) continue;
+    const int r = r0 + rb;
+    if (tid == 0) acquire_agent();
     __syncthreads();
-    if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    if (!gmm_exchange_rows(a, a.xchg, K, w, r, l_mom, l_mom, tid, TB, &sm.last)) return;
-  }
-  if (a.advance_in_tail) advance_block(a, K, w + 1, r, sm.adv, sm.spec, true, tid, TB);     // starts with a barrier after staging
-  __syncthreads();
-  POCS_STEP_STAMP(5);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The whole run in ONE launch: every task (w, r, j) of the call's W waypoints x R runs x S slices,
-// handed out in that order from a queue (one returning atomic per task and block).  A task of
-// waypoint w > 0 needs `ready[r] >= w`, published by whoever closed (r, w-1) -- a task handed out
-// earlier to a block that is running, so the wait always ends, however many blocks are resident.
-//
-// Nothing synchronises the grid, and nothing synchronises a block either: its waves run the block's
-// tasks one after the other, each at its own pace, through a small pipeline kept in LDS.
-//   * One wave is the LOADER of task n+1 (wave (n+1) mod 8: the role goes round): at the start of its
-//     share of task n (when it has no sample stores in flight: a wave's loads, atomics and stores
-//     complete in issue order, and write-through stores are slow to complete) it takes task n+1 from
-//     the queue and, if that task's parameters are published, stages them and the culled obstacle
-//     table into buffer (n+1) % 3; otherwise it tries again, and then waits, after its share of the
-//     body.  seq[b] = n+2 hands the buffer to the other waves, who wait for it in LDS only.
-//   * A wave that has sampled its share of task n and drained its stores counts itself in done[b].
-//     The wave that counts last CLOSES the task for the block: rows -> the task's write-through
-//     partial row -> drain -> ticket (r, w).  The wave that draws the run's last ticket acquires,
-//     adds the run's partial rows, advances the mixture of run r to waypoint w+1 (one wave:
-//     advance_wave) and publishes ready[r] = w+1 -- while its block's other waves and every other
-//     block are already sampling.  freed[b] = n+1 gives the buffer back to wave 0.
-// With R * S ~ 2.2 x the resident blocks per waypoint the tasks of waypoint w+1 come up in the queue
-// when those of waypoint w have long been closed: the loader finds them published, and a block goes
-// from one body straight into the next.  Every wait is bounded (2 s): a wave that gives up sets the
-// call's give-up word and the block's quit word, everybody leaves at the next look, and the host
-// reports POCS_E_DEVICE.
-// ---------------------------------------------------------------------------------------------
-// task buffers of k_gmm_run: three while two blocks of them fit a CU's 160 KB of LDS (K <= 5), two beyond
-#define POCS_RUN_NB_OF(K) ((K) <= 5 ? 3 : 2)
-__device__ __forceinline__ unsigned lds_load(const unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_store(unsigned* p, unsigned v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// LDS words written by another wave of the block: order our LDS accesses around them
-__device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
-__device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-
-// Spin (whole wave, uniform) until *word == want, in LDS.  false: the block is quitting.
-__device__ __forceinline__ bool wait_lds(const unsigned* word, const unsigned want, unsigned* quit, unsigned* abort_word) {
-  const unsigned long long t0 = wall_clock64();                         // 100 MHz
-  unsigned polls = 0;
-  while (lds_load(word) != want) {
-    __builtin_amdgcn_s_sleep(1);
-    if ((++polls & 63u) == 0u) {
-      if (lds_load(quit) != 0u) return false;
-      if (wall_clock64() - t0 > 200000000ull) {                         // 2 s
-        __hip_atomic_store(abort_word, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lds_store(quit, 1u);
-        return false;
-      }
-    }
-  }
-  lds_acquire();
-  return true;
-}
-// ... until ready[r] >= need, in global memory (one lane polls; the caller acquires afterwards).
-__device__ __forceinline__ bool wait_ready(unsigned* ready, const unsigned need, unsigned* quit, unsigned* abort_word) {
-  const unsigned long long t0 = wall_clock64();
-  unsigned polls = 0;
-  while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-    __builtin_amdgcn_s_sleep(4);
-    if ((++polls & 63u) == 0u) {
-      if (lds_load(quit) != 0u) return false;
-      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-          wall_clock64() - t0 > 200000000ull) {
-        __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lds_store(quit, 1u);
-        return false;
-      }
-    }
-  }
-  return true;
-}
-
-// The loader wave of task `next` (= n + 1), all 64 lanes: stage it.  pending = the queue number
-// already drawn for it (0xfffffffe: none yet).  blocking = wait for the buffer and for the task's
-// parameters if need be.  Returns true when the task is staged and handed over (or the queue is
-// exhausted: task_id >= total tells everybody to leave).
-template <int K, int TB, int NB>
-__device__ __forceinline__ bool gmm_stage_next(const pocs_gmm_launch& a, gmm_smem<K, TB, NB>& sm, const unsigned next,
-                                               unsigned& pending, const bool blocking, const int lane) {
-  const unsigned per_wp = (unsigned)a.nruns * (unsigned)a.slices;
-  const unsigned total = per_wp * (unsigned)a.W;
-  const int b = (int)(next % (unsigned)NB);
-  if (next >= (unsigned)NB) {                        // the buffer's previous task (next - NB) must be closed
-    const unsigned want = next - (unsigned)NB + 1u;
-    if (lds_load(&sm.freed[b]) != want) {
-#if defined(POCS_TASK_STAMPS)
-      if (lane == 0) atomicAdd(&g_stamps[blocking ? 11 : 10], 1ull);
-#endif
-      if (!blocking) return false;
-      if (!wait_lds(&sm.freed[b], want, &sm.quit, &a.sync[POCS_SYNC_ABORT])) return false;
-    }
-    lds_acquire();
-  }
-  if (pending == 0xfffffffeu) {
-    unsigned t = 0u;
-    if (lane == 0) {
-      t = __hip_atomic_fetch_add(&a.sync[POCS_SYNC_HEAD], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) t = 0xffffffffu;
-    }
-    pending = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-  }
-  const unsigned t = pending;
-  if (t < total) {
-    const int w = __builtin_amdgcn_readfirstlane((int)(t / per_wp));
-    const int r = __builtin_amdgcn_readfirstlane((int)((t - (unsigned)w * per_wp) / (unsigned)a.slices));
-    if (w > 0) {
-      unsigned have = 0u;
-      if (lane == 0) have = __hip_atomic_load(&a.sync[POCS_SYNC_READY + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((unsigned)__builtin_amdgcn_readfirstlane((int)have) < (unsigned)w) {
-#if defined(POCS_TASK_STAMPS)
-        if (lane == 0) atomicAdd(&g_stamps[blocking ? 15 : 14], 1ull);
-#endif
-        if (!blocking) return false;
-        if (!wait_ready(&a.sync[POCS_SYNC_READY + r], (unsigned)w, &sm.quit, &a.sync[POCS_SYNC_ABORT])) return false;
-      }
-      acquire_agent();                               // the poll matched: ONE acquire, then the loads
-    }
-    const int slot = (int)(t - (unsigned)w * per_wp) - r * a.slices;
-    stage_batched<2>(sm.par[b], K * POCS_PARAM_STRIDE, lane, 64, [&](int j) -> double {
-      return load_wt(&a.param[((size_t)r * a.W + w) * (K * POCS_PARAM_STRIDE) + j]); });
-    if (lane == 0) {
-      long long cb, ce;
-      gmm_slice_chunks(a, slot, &cb, &ce);
-      sm.seed[b] = a.hdr[r].seed;
-      sm.c_begin[b] = cb; sm.c_end[b] = ce;
-      sm.tw[b] = w; sm.tr[b] = r; sm.tslot[b] = slot;
-    }
-    __threadfence_block();
-    __builtin_amdgcn_wave_barrier();
-    gmm_cull(a, sm, b, lane);
-  }
-  if (lane == 0) {
-    sm.done[b] = 0u;
-    sm.task_id[b] = t;
-  }
-  lds_release();
-  if (lane == 0) lds_store(&sm.seq[b], next + 1u);
-  pending = 0xfffffffeu;
-  return true;
-}
-
-template <int K, bool STORE, int TB>
-__global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_run(pocs_gmm_launch a) {
-  constexpr int NB = POCS_RUN_NB_OF(K);
-  typedef gmm_smem<K, TB, NB> smem_t;
-  constexpr int NC = smem_t::NC, RB = smem_t::RB, NW = TB / 64;
-  __shared__ smem_t sm;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned per_wp = (unsigned)a.nruns * (unsigned)a.slices;
-  const unsigned total = per_wp * (unsigned)a.W;
-  gmm_stage_static(a, sm);
-  if (tid < NB) { sm.seq[tid] = 0u; sm.done[tid] = 0u; sm.freed[tid] = 0u; sm.task_id[tid] = 0u; }
-  if (tid == 0) { sm.lock = 0u; sm.quit = 0u; }
-  __syncthreads();                                   // the only barrier of the launch
-  unsigned pending = 0xfffffffeu;
-  if (wave == 0 && !gmm_stage_next(a, sm, 0u, pending, true, lane)) return;
-#if defined(POCS_TASK_STAMPS)
-  unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long last_ = wall_clock64();
-  const unsigned long long t_begin_ = last_;
-#endif
-  for (unsigned n = 0;; ++n) {
-    const int b = (int)(n % (unsigned)NB);
-    // the loader of task n + 1 is wave (n + 1) mod NW: the role goes round, so that its round trips (and
-    // the closing of a task, which falls to whichever wave finishes last) delay every wave alike
-    const bool loader = wave == (int)((n + 1u) % (unsigned)NW);
-    if (!wait_lds(&sm.seq[b], n + 1u, &sm.quit, &a.sync[POCS_SYNC_ABORT])) break;
-    POCS_STAMP(0);
-    const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)sm.task_id[b]);
-    if (t >= total) break;
-    const int w = __builtin_amdgcn_readfirstlane(sm.tw[b]), r = __builtin_amdgcn_readfirstlane(sm.tr[b]);
-    const int slot = __builtin_amdgcn_readfirstlane(sm.tslot[b]);
-    const uint64_t seed = (uint64_t)uniform64((long long)sm.seed[b]);
-    const long long c_begin = uniform64(sm.c_begin[b]), c_end = uniform64(sm.c_end[b]);
-    bool staged = true;
-    if (loader) staged = gmm_stage_next(a, sm, n + 1u, pending, false, lane);
-    POCS_STAMP(1);
-#if defined(POCS_TASK_STAMPS)
-    gmm_body<K, STORE, true, TB>(a, &sm.tab, sm.par[b], sm.keep[b], __builtin_amdgcn_readfirstlane(sm.nkeep[b]), sm.red[b], w, r,
-                                 seed, c_begin, c_end, st_, last_);
-#else
-    gmm_body<K, STORE, true, TB>(a, &sm.tab, sm.par[b], sm.keep[b], __builtin_amdgcn_readfirstlane(sm.nkeep[b]), sm.red[b], w, r,
-                                 seed, c_begin, c_end);
-#endif
-    // this wave's share is sampled: drain its stores, count it in
-    drain_stores();
+    double* const l_mom = advance_ptrs(a, K, w + 1, r, sm.adv()).l_mom;
+    gmm_close_sums<K>(a, w, r, sm.par[rb], sm.stage(), l_mom, tid, TB);
     POCS_STAMP(5);
-    lds_release();
-    unsigned pos = 0u;
-    if (lane == 0) pos = __hip_atomic_fetch_add(&sm.done[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if ((unsigned)__builtin_amdgcn_readfirstlane((int)pos) == (unsigned)NW - 1u) {
-    // ---- the block's last wave for this task closes it
-    lds_acquire();
-    for (int c = lane; c < NC; c += 64)
-      store_wt(&a.partial[((size_t)r * a.slices + slot) * NC + c], gmm_row_total<NC, RB>(sm.red[b], c));
-    drain_stores();
-    unsigned tk = 0u;
-    if (lane == 0) tk = __hip_atomic_fetch_add(&a.ticket[(size_t)r * a.W + w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((unsigned)__builtin_amdgcn_readfirstlane((int)tk) == (unsigned)a.slices - 1u) {
-      // ---- ... and the run's last block for this waypoint closes (r, w)
-#if defined(POCS_TASK_STAMPS)
-      const unsigned long long f0_ = wall_clock64();
-#endif
-      acquire_agent();
-      bool mine = true;                              // the advance scratch is one wave's at a time
-      {
-        const unsigned long long t0 = wall_clock64();
-        for (;;) {
-          unsigned old = 1u;
-          if (lane == 0) { unsigned exp = 0u; old = __hip_atomic_compare_exchange_strong(&sm.lock, &exp, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 0u : 1u; }
-          if (__builtin_amdgcn_readfirstlane((int)old) == 0) break;
-          __builtin_amdgcn_s_sleep(2);
-          if (lds_load(&sm.quit) != 0u || wall_clock64() - t0 > 200000000ull) { mine = false; break; }
-        }
-      }
-      if (!mine) {
-        __hip_atomic_store(&a.sync[POCS_SYNC_ABORT], 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lds_store(&sm.quit, 1u);
-        break;
-      }
-      lds_acquire();
-#if defined(POCS_TASK_STAMPS)
-      const unsigned long long f1_ = wall_clock64();
-#endif
-      double* const l_mom = advance_ptrs(a, K, w + 1, r, sm.adv).l_mom;
-      gmm_close_sums<K, RB>(a, w, r, sm.par[b], &sm.red[b][0][0], l_mom, lane, 64,
-                            [] { __threadfence_block(); __builtin_amdgcn_wave_barrier(); });
-#if defined(POCS_TASK_STAMPS)
-      const unsigned long long f2_ = wall_clock64();
-#endif
-      if (w + 1 < a.W) {
-        advance_wave(a, K, w + 1, r, sm.adv, lane);                    // ends with its stores drained
-        if (lane == 0)
-          __hip_atomic_store(&a.sync[POCS_SYNC_READY + r], (unsigned)(w + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#if defined(POCS_TASK_STAMPS)
-      if (lane == 0) {
-        const unsigned long long f3_ = wall_clock64();
-        atomicAdd(&g_stamps[16], f1_ - f0_); atomicAdd(&g_stamps[17], f2_ - f1_); atomicAdd(&g_stamps[18], f3_ - f2_);
-        atomicAdd(&g_stamps[19], 1ull);
-      }
-#endif
-      lds_release();
-      if (lane == 0) lds_store(&sm.lock, 0u);
+    if (a.exchange_in_tail) {
+      // sharded: the run's closer is also its messenger -- this shard's moments go to every rank, the world's
+      // come back summed in rank order, and the mixture advances here (no launch, no host, between waypoints)
+      __syncthreads();
+      if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+      if (!gmm_exchange_rows(a, a.xchg, K, w, r, l_mom, l_mom, tid, TB, &sm.nkeep[0] /* free by now */)) return;
     }
-    lds_release();
-    if (lane == 0) lds_store(&sm.freed[b], n + 1u);
-    }
+    if (a.advance_in_tail) advance_block(a, K, w + 1, r, sm.adv(), sm.spec(), true, tid, TB);     // starts with a barrier after staging
+    __syncthreads();
     POCS_STAMP(6);
-    // the loader could not stage the next task before its share of this one (not published yet, or the
-    // buffer still in use): now it waits -- AFTER counting itself in above, the closing of this very
-    // task may be what the next one is waiting for
-    if (loader && !staged && !gmm_stage_next(a, sm, n + 1u, pending, true, lane)) break;
-    POCS_STAMP(7);
-#if defined(POCS_TASK_STAMPS)
-    st_[9] += 1;
+#if defined(POCS_STAMPS)
+    if (tid == 0) atomicAdd(&g_stamps[14], 1ull);
 #endif
   }
-#if defined(POCS_TASK_STAMPS)
-  if (lane == 0) {
-    const unsigned long long life_ = wall_clock64() - t_begin_;
-    for (int i = 0; i < 10; ++i) atomicAdd(&g_stamps[i], st_[i]);
-    atomicAdd(&g_stamps[12], life_);
-    atomicAdd(&g_stamps[13], 1ull);
-  }
-#endif
 }
 
 // MC kernels: blockIdx.y = run of the batch (its own seed, its own noisy controls, its own slice
@@ -1315,19 +1077,25 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_count(pocs_mc_launch a) {
 template <int K>
 hipError_t launch_gmm_k(const pocs_gmm_launch& a, hipStream_t s) {
   constexpr int TB = POCS_GMM_BLOCK_OF(K);
-  if (a.store) hipLaunchKernelGGL((k_gmm_step<K, true, TB>), dim3(a.slices, a.nruns), dim3(TB), 0, s, a);
-  else         hipLaunchKernelGGL((k_gmm_step<K, false, TB>), dim3(a.slices, a.nruns), dim3(TB), 0, s, a);
-  return hipGetLastError();
-}
-template <int K>
-hipError_t launch_gmm_run_k(int nblk, const pocs_gmm_launch& a, hipStream_t s) {
-  constexpr int TB = POCS_GMM_BLOCK_OF(K);
-  if (a.store) hipLaunchKernelGGL((k_gmm_run<K, true, TB>), dim3(nblk), dim3(TB), 0, s, a);
-  else         hipLaunchKernelGGL((k_gmm_run<K, false, TB>), dim3(nblk), dim3(TB), 0, s, a);
+  if (a.store) hipLaunchKernelGGL((k_gmm_step<K, true, TB>), dim3(a.blocks), dim3(TB), 0, s, a);
+  else         hipLaunchKernelGGL((k_gmm_step<K, false, TB>), dim3(a.blocks), dim3(TB), 0, s, a);
   return hipGetLastError();
 }
 
 }  // namespace
+
+#if defined(POCS_STAMPS)
+extern "C" void pocs_stamps_report() {
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) != hipSuccess || h[15] == 0) return;
+  const double nb = (double)h[15], nc = (double)(h[14] ? h[14] : 1);
+  fprintf(stderr, "[stamps] %.0f blocks, %.0f closers; per block (us): head %.2f | units %.2f | -> barrier %.2f | rows + drain + barrier %.2f | "
+          "ticket + barrier %.2f ; per closer: close_sums %.2f | advance %.2f\n", nb, nc, 0.01 * h[0] / nb, 0.01 * h[1] / nb, 0.01 * h[2] / nb,
+          0.01 * h[3] / nb, 0.01 * h[4] / nb, 0.01 * h[5] / nc, 0.01 * h[6] / nc);
+  unsigned long long z[16] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
+}
+#endif
 
 hipError_t pocs_launch_gmm_step(int K, const pocs_gmm_launch& a, hipStream_t s) {
   switch (K) {
@@ -1339,43 +1107,6 @@ hipError_t pocs_launch_gmm_step(int K, const pocs_gmm_launch& a, hipStream_t s) 
     case 6: return launch_gmm_k<6>(a, s);
     case 7: return launch_gmm_k<7>(a, s);
     case 8: return launch_gmm_k<8>(a, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-#if defined(POCS_TASK_STAMPS)
-static hipError_t launch_gmm_run_plain(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s);
-hipError_t pocs_launch_gmm_run(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s) {
-  unsigned long long z[32] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
-  const hipError_t e = launch_gmm_run_plain(K, nblk, a, s);
-  (void)hipStreamSynchronize(s);
-  unsigned long long h[32];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) == hipSuccess && h[13] > 0) {
-    static const char* names[8] = {"wait-seq", "decode+stage-try", "prologue", "loop", "flush", "drain", "count+close", "stage-blocking"};
-    const double nw = (double)h[13], tasks = (double)h[9];
-    fprintf(stderr, "stamps: %g waves, %g wave-tasks, mean wave lifetime %.1f us; per wave-task (us):", nw, tasks, 0.01 * h[12] / nw);
-    for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.2f", names[i], 0.01 * (double)h[i] / tasks);
-    fprintf(stderr, "; of %g tasks the loader found: buffer busy %llu (again when blocking %llu), not published %llu (again %llu)\n",
-            tasks / 8.0, h[10], h[11], h[14], h[15]);
-    if (h[19]) fprintf(stderr, "stamps: %llu run-waypoints closed; per closing (us): acquire+lock %.2f, adding the rows %.2f, advance+publish %.2f\n", h[19],
-                       0.01 * (double)h[16] / (double)h[19], 0.01 * (double)h[17] / (double)h[19], 0.01 * (double)h[18] / (double)h[19]);
-  }
-  return e;
-}
-static hipError_t launch_gmm_run_plain(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s) {
-#else
-hipError_t pocs_launch_gmm_run(int K, int nblk, const pocs_gmm_launch& a, hipStream_t s) {
-#endif
-  switch (K) {
-    case 1: return launch_gmm_run_k<1>(nblk, a, s);
-    case 2: return launch_gmm_run_k<2>(nblk, a, s);
-    case 3: return launch_gmm_run_k<3>(nblk, a, s);
-    case 4: return launch_gmm_run_k<4>(nblk, a, s);
-    case 5: return launch_gmm_run_k<5>(nblk, a, s);
-    case 6: return launch_gmm_run_k<6>(nblk, a, s);
-    case 7: return launch_gmm_run_k<7>(nblk, a, s);
-    case 8: return launch_gmm_run_k<8>(nblk, a, s);
     default: return hipErrorInvalidValue;
   }
 }

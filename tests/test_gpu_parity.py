@@ -1,8 +1,9 @@
 """Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
-same seeded inputs.  Integer work (collision flags, hit counters, survivor counts) must be
-bit-exact; floating-point sums are compared at a relative 1e-10 (the oracle adds in sample order,
-the GPU in a fixed tree); probabilities at 1e-9 -- well inside the 1e-6 absolute tolerance the
-north star states for the GMM path."""
+same seeded inputs.  Everything is compared BIT FOR BIT: integer work (collision flags, hit counters,
+survivor counts), samples and particles, and -- since numerics v7 fixes the summation tree of the
+moment sums, which the oracle restates -- the floating-point sums, hence every mixture state and every
+probability of a free-running estimation, at any sample count and for any number of runs per launch.
+(The north star's tolerance for the GMM path is 1e-6 absolute; `==` is stricter.)"""
 import math
 
 import numpy as np
@@ -11,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SEED = 0x5EED0001
-REL = 1e-10
+WEYL = 0x9E3779B97F4A7C15            # effective seed of the r-th run of a context = seed + r * WEYL (mod 2^64)
 
 
 @pytest.fixture(scope="module")
@@ -23,8 +24,7 @@ def ctx(pocs):
 
 def close_moments(got, want):
     assert np.array_equal(got[..., :2], want[..., :2]), "survivor / collision counts differ"
-    scale = np.maximum(np.abs(want[..., 2:]), 1.0)
-    assert np.max(np.abs(got[..., 2:] - want[..., 2:]) / scale) < REL
+    assert np.array_equal(got, want), "moment sums differ"
 
 
 def test_host_chain_is_bitwise_the_oracles(ctx, orc, plan, env):
@@ -76,8 +76,8 @@ def test_cfg1_exact_shape(ctx, orc, plan, env):
         p = ctx.run_gmm_estimation()
         want = orc.run_gmm(cfg, seed, 1000, want_samples=True)
         got_m = np.array([ctx.moments(w, 3) for w in range(56)])
-        assert np.array_equal(got_m[..., :2], want["moments"][..., :2])
-        assert np.array_equal(ctx.waypoint_probabilities(), want["probs"]) and abs(p - want["prob"]) < 1e-12
+        assert np.array_equal(got_m, want["moments"])
+        assert np.array_equal(ctx.waypoint_probabilities(), want["probs"]) and p == want["prob"]
         assert np.array_equal(ctx.gmm_samples(1000)[1], want["flags"])
         ctx.set_seed(seed)
         assert ctx.run_simulation() == orc.run_mc(cfg, seed, 1000)[0] / 1000
@@ -107,7 +107,7 @@ def test_gmm_first_waypoint_samples_bit_exact(ctx, orc, plan, env):
     assert np.array_equal(flags, want["flags"])
     assert np.array_equal(xyz, want["samples"])
     close_moments(ctx.moments(0, 3), want["moments"][0])
-    assert abs(p - want["prob"]) < 1e-15
+    assert p == want["prob"]
 
 
 def test_gmm_two_million_samples_bit_exact(ctx, orc, plan, env):
@@ -122,7 +122,7 @@ def test_gmm_two_million_samples_bit_exact(ctx, orc, plan, env):
     xyz, flags = ctx.gmm_samples(N)
     assert np.array_equal(flags, want["flags"])
     assert np.array_equal(xyz, want["samples"])
-    assert np.array_equal(ctx.moments(0, 2)[:, :2], want["moments"][0][:, :2])
+    assert np.array_equal(ctx.moments(0, 2), want["moments"][0])
 
 
 @pytest.mark.parametrize("K,N", [(1, 3000), (3, 10000), (8, 6000), (3, 100)])
@@ -136,56 +136,108 @@ def test_gmm_matches_oracle(ctx, orc, plan, env, K, N):
     got_s = np.array([ctx.gmm_state_raw(w, K) for w in range(W)])
     chain = orc.host_chain(cfg, seed)
 
-    # (1) stage by stage, the oracle fed with the GPU's own inputs: every stage must agree to the
-    #     last bit, except the order in which the moment sums are added
+    # (1) stage by stage, the oracle fed with the GPU's own inputs: every stage must agree to the last bit
     st0 = orc.gmm_advance(cfg, orc.gmm_initial_state(cfg), None)
     assert np.array_equal(got_s[0][:, :14], st0[:, :14])
     for w in range(W):
         mom, samples, flags, comp = orc.gmm_waypoint(cfg, seed, w, got_s[w], 0, N, want_samples=True)
-        assert np.array_equal(got_m[w][:, :2], mom[:, :2]), w              # survivors / collisions
-        scale = np.maximum(np.abs(mom[:, 2:]), mom[:, :1] * 1e-3 + 1e-300)
-        assert np.max(np.abs(got_m[w][:, 2:] - mom[:, 2:]) / scale) < 1e-11, w
+        assert np.array_equal(got_m[w], mom), w                            # survivors / collisions / the nine sums
         if w + 1 < W:                                                      # device EKF / truncation / Cholesky
             nxt = orc.gmm_advance(cfg, got_s[w], got_m[w], chain["applied"][w], chain["Mdiag"][w], chain["z"][w])
             assert np.array_equal(got_s[w + 1][:, :14], nxt[:, :14]), w
     xyz, gflags = ctx.gmm_samples(N)                                       # last waypoint, as stored in HBM
     assert np.array_equal(gflags, flags) and np.array_equal(xyz, samples)
 
-    # (2) free running: both sides from the seed alone.  The single-pass covariance of the
-    #     reference (op_cov) cancels ~4 digits, so summation order shows up at 1e-11 in the state
-    #     and is carried along the 56 steps; flags, hence probabilities, still agree exactly here.
+    # (2) free running: both sides from the seed alone, and still every bit
     want = orc.run_gmm(cfg, seed, N)
-    assert np.array_equal(got_m[..., :2], want["moments"][..., :2])
+    assert np.array_equal(got_m, want["moments"])
     assert np.array_equal(ctx.waypoint_probabilities(), want["probs"])
-    assert abs(p - want["prob"]) < 1e-12
-    assert np.allclose(got_s[..., 0:3], want["states"][..., 0:3], rtol=0, atol=1e-8)
-    assert np.allclose(got_s[..., 3:12], want["states"][..., 3:12], rtol=1e-5, atol=1e-12)
-    assert np.allclose(got_s[..., 12], want["states"][..., 12], rtol=1e-12, atol=0)
+    assert p == want["prob"]
+    assert np.array_equal(got_s[..., :14], want["states"][..., :14])
 
 
-def test_gmm_one_million_samples_within_1e6(ctx, orc, plan, env):
-    """configs[1] of BASELINE.json at full size: bundled plan, 3 components, 10^6 samples."""
+def test_gmm_one_million_samples_bit_exact(ctx, orc, plan, env):
+    """configs[1] of BASELINE.json at full size: bundled plan, 3 components, 10^6 samples, free running:
+    within the north star's 1e-6 -- in fact equal."""
     cfg = orc.config(plan, env, K=3)
     N = 1000000
     ctx.configure(plan, env, K=3, N=N, seed=SEED)
     p = ctx.run_gmm_estimation()
     want = orc.run_gmm(cfg, SEED, N)
     assert abs(p - want["prob"]) <= 1e-6                       # the stated tolerance
-    assert np.max(np.abs(ctx.waypoint_probabilities() - want["probs"])) <= 1e-6
+    assert p == want["prob"] and np.array_equal(ctx.waypoint_probabilities(), want["probs"])
     got_m = np.array([ctx.moments(w, 3) for w in range(cfg.W)])
-    assert np.array_equal(got_m[..., :2], want["moments"][..., :2])
+    assert np.array_equal(got_m, want["moments"])
+
+
+def _run_of_batch(c, r, K, W):
+    c.select_batch_run(r)
+    return (np.array([c.moments(w, K) for w in range(W)]), c.waypoint_probabilities().copy(),
+            np.array([c.gmm_state_raw(w, K) for w in range(W)])[..., :14])
+
+
+@pytest.mark.parametrize("R", [20, 64])
+def test_timed_launch_shapes_against_the_oracle(pocs, orc, plan, env, R):
+    """The shapes bench.py times -- 10^6 samples, K = 3, 20 runs per call (the driver's invocation) and 64
+    (the default) -- compared with the oracle: run 0 and run R - 1 of the batch on their effective seeds,
+    every waypoint's moments, probabilities and mixture, bit for bit; and the whole batch through
+    run-ahead (one command per run, the OpenRAVE adapter's default) gives the same bits again."""
+    N, K = 1_000_000, 3
+    cfg = orc.config(plan, env, K=K)
+    with pocs.Context(0) as c:
+        c.configure(plan, env, K=K, N=N, seed=SEED)
+        c.set_batch(R)
+        p0 = c.run_gmm_estimation()
+        finals = list(c.batch_probabilities())
+        got = {r: _run_of_batch(c, r, K, cfg.W) for r in (0, 1, R - 1)}
+        for r in (0, R - 1):
+            want = orc.run_gmm(cfg, (SEED + r * WEYL) % 2**64, N)
+            assert np.array_equal(got[r][0], want["moments"]), r
+            assert np.array_equal(got[r][1], want["probs"]) and finals[r] == want["prob"], r
+            assert np.array_equal(got[r][2], want["states"][..., :14]), r
+        assert p0 == finals[0]
+        c.set_batch(1)
+        c.set_option(pocs.OPT_RUN_AHEAD, 64)
+        c.set_seed(SEED)
+        for r in range(2):
+            assert c.run_gmm_estimation() == finals[r]
+            assert np.array_equal(np.array([c.moments(w, K) for w in range(cfg.W)]), got[r][0]), r
+            assert np.array_equal(c.waypoint_probabilities(), got[r][1]), r
+
+
+@pytest.mark.parametrize("K,N,R", [(3, 300000, 7), (8, 150000, 3), (1, 2_000_000, 1), (2, 40001, 20), (3, 5001, 33)])
+def test_runs_per_launch_do_not_change_a_bit(pocs, plan, env, K, N, R):
+    """The moment sums are defined on a run's virtual slices, not on the launch: R runs per call (blocks
+    that work on several slices, some of them on two runs), one run per call and eager launches give
+    the same moments, states and samples for every run, and the same again when repeated."""
+    with pocs.Context(0) as c:
+        c.configure(plan, env, K=K, N=N, seed=123)
+        singles = []
+        for r in range(min(R, 3)):
+            c.run_gmm_estimation()
+            singles.append(_run_of_batch(c, 0, K, 56) + (c.gmm_samples(N),))
+        c.set_batch(R)
+        for rep in range(2):
+            if rep == 1:
+                c.set_option(pocs.OPT_USE_GRAPH, 0)
+            c.set_seed(123)
+            c.run_gmm_estimation()
+            for r in range(min(R, 3)):
+                got = _run_of_batch(c, r, K, 56)
+                assert all(np.array_equal(a, b) for a, b in zip(got, singles[r][:3])), (rep, r)
+                x, f = c.gmm_samples(N)
+                assert np.array_equal(f, singles[r][3][1]) and np.array_equal(x, singles[r][3][0]), (rep, r)
 
 
 def test_gmm_variants_agree(ctx, pocs, plan, env):
-    """One launch per waypoint (k_gmm_step, the default) vs the whole run in one queue-driven launch
-    (k_gmm_run), graph replay vs eager launches, with and without the sample store, and the
-    per-waypoint step API: the same tasks with the same arithmetic, so everything is bitwise the same."""
+    """Graph replay vs eager launches, with and without the sample store, with the profiling events,
+    and the per-waypoint step API: the same units with the same arithmetic, so everything is bitwise
+    the same."""
     ctx.configure(plan, env, K=3, N=20000, seed=11)
     base = ctx.run_gmm_estimation()
     base_probs = ctx.waypoint_probabilities().copy()
     base_m = ctx.moments(30, 3).copy()
-    base_xyz, base_flags = ctx.gmm_samples(20000)
-    for opt, val in ((pocs.OPT_USE_GRAPH, 0), (pocs.OPT_STORE_SAMPLES, 0), (pocs.OPT_PROFILE, 1), (pocs.OPT_PERSISTENT, 1)):
+    for opt, val in ((pocs.OPT_USE_GRAPH, 0), (pocs.OPT_STORE_SAMPLES, 0), (pocs.OPT_PROFILE, 1)):
         ctx.set_option(opt, val)
         ctx.set_seed(11)
         assert ctx.run_gmm_estimation() == base
@@ -194,14 +246,6 @@ def test_gmm_variants_agree(ctx, pocs, plan, env):
         if opt == pocs.OPT_PROFILE:
             ms, n = ctx.kernel_time()
             assert n == 56 and ms > 0                            # one launch per waypoint
-        if opt == pocs.OPT_PERSISTENT:
-            xyz, flags = ctx.gmm_samples(20000)
-            assert np.array_equal(xyz, base_xyz) and np.array_equal(flags, base_flags)
-            ctx.set_option(pocs.OPT_PROFILE, 1)
-            ctx.set_seed(11)
-            assert ctx.run_gmm_estimation() == base
-            assert ctx.kernel_time()[1] == 1                     # ONE launch covers the 56 waypoints
-            ctx.set_option(pocs.OPT_PROFILE, 0)
         ctx.set_option(opt, 1 - val)
     ctx.set_seed(11)
     again = ctx.run_gmm_estimation()                             # graph replayed a second time
@@ -211,32 +255,32 @@ def test_gmm_variants_agree(ctx, pocs, plan, env):
     for w in range(56):
         ctx.gmm_step_local(w)
     assert ctx.gmm_end() == base
+    with pytest.raises(pocs.PocsError):                          # the queue-driven kernel of round 2 is retired
+        ctx.set_option(pocs.OPT_PERSISTENT, 1)
+    ctx.set_option(pocs.OPT_PERSISTENT, 0)
 
 
-@pytest.mark.parametrize("K,N,R", [(3, 300000, 7), (8, 150000, 3), (1, 2_000_000, 1), (2, 40001, 20)])
-def test_persistent_kernel_under_uneven_load(pocs, plan, env, K, N, R):
-    """k_gmm_run hands its tasks out from a queue and carries the waypoint dependency of each run in a
-    `ready` word; which block runs what, and when, varies from launch to launch.  Sizes chosen so that
-    runs finish their waypoints at different times and blocks meet parameters published by other
-    blocks: every repetition must be bitwise what one launch per waypoint gives (moments of every
-    waypoint and run, states, last samples), and bitwise the same again."""
-    with pocs.Context(0) as c:
-        c.configure(plan, env, K=K, N=N, seed=123)
-        c.set_batch(R)
-        c.run_gmm_estimation()                                  # one launch per waypoint (the default)
-        want_p = list(c.batch_probabilities())
-        want_m = np.array([c.moments(w, K) for w in range(56)])
-        want_s = c.gmm_state_raw(55, K).copy()
-        want_x, want_f = c.gmm_samples(N)
-        c.set_option(pocs.OPT_PERSISTENT, 1)
-        for rep in range(4):
-            c.set_seed(123)
-            c.run_gmm_estimation()
-            assert list(c.batch_probabilities()) == want_p, rep
-            assert np.array_equal(np.array([c.moments(w, K) for w in range(56)]), want_m), rep
-            assert np.array_equal(c.gmm_state_raw(55, K), want_s), rep
-            x, f = c.gmm_samples(N)
-            assert np.array_equal(f, want_f) and np.array_equal(x, want_x), rep
+@pytest.mark.parametrize("mc", [False, True])
+def test_graph_replays_survive_readbacks(pocs, plan, env, mc):
+    """A caller that reads mixture states and samples back between two runs (dozens of small synchronous
+    copies plus a large one, results kept) and then runs again: every replay of the captured graph must give
+    what a fresh context gives.  (With memset / memcpy nodes inside the graph, ROCm 7.2 lost the third
+    replay of exactly this sequence -- round 2's library included; the graphs hold kernel nodes only now.)"""
+    K, N = 3, 300000
+    def sequence(graph):
+        out, keep = [], []
+        with pocs.Context(0) as c:
+            c.configure(plan, env, K=K, N=N, seed=123)
+            c.set_num_particles(N)
+            c.set_option(pocs.OPT_USE_GRAPH, graph)
+            for i in range(6):
+                out.append(c.run_simulation() if mc else c.run_gmm_estimation())
+                if mc:
+                    keep.append(c.particles(N))
+                else:
+                    keep.append((np.array([c.gmm_state_raw(w, K) for w in range(56)]), c.gmm_samples(N)))
+        return out
+    assert sequence(1) == sequence(0)
 
 
 def test_batch_equals_consecutive_single_runs(ctx, plan, env):
@@ -689,20 +733,12 @@ def test_run_ahead_serves_the_same_runs(pocs, plan, env, mc):
 
     one, ahead, auto = sequence(1), sequence(4), sequence(0)      # 0: the depth sized from N (64 here)
     assert len(one) == len(ahead) == len(auto) == 16
-    tol = 0.0 if mc else 2.0 / N          # GMM moments are summed over another block layout when batched
     for i, ((p1, _), (p3, s3)) in enumerate(zip(one, auto)):
-        assert abs(p1 - p3) <= tol and s3["bp"] == [p3], i
+        assert p1 == p3 and s3["bp"] == [p3], i
     for i, ((p1, s1), (p2, s2)) in enumerate(zip(one, ahead)):
-        assert abs(p1 - p2) <= tol, i
+        assert p1 == p2, i
         assert s2["bp"] == [p2], i                           # the caller asked for one run at a time
-        if mc:
-            assert _same(s1, s2), i
-        else:
-            assert np.array_equal(s1["app"], s2["app"]) and np.array_equal(s1["z"], s2["z"]) and np.array_equal(s1["mu"], s2["mu"]), i
-            assert np.array_equal(s1["m7"][:, :2], s2["m7"][:, :2]), i            # survivor / collision counts
-            assert np.allclose(s1["m55"], s2["m55"], rtol=1e-6, atol=1e-9), i
-            assert np.allclose(s1["st"], s2["st"], rtol=1e-5, atol=1e-9), i
-            assert np.mean(s1["flags"] != s2["flags"]) < 1e-3 and np.allclose(s1["xyz"], s2["xyz"], atol=1e-6), i
+        assert _same(s1, s2), i                              # every getter, bit for bit: the launch shape changes nothing
     assert one[14][0] == one[0][0] and ahead[14][0] == ahead[0][0]               # after the rewind
     assert len({p for p, _ in one[:11]}) == 11                                   # every run redraws
 
@@ -720,8 +756,7 @@ def test_run_ahead_with_alternating_paths(pocs, plan, env):
                 out.append(c.run_gmm_estimation() if call == "G" else c.run_simulation())
             return out
     one, ahead = sequence(1), sequence(4)
-    assert all(abs(a - b) <= 2.0 / 3000 for a, b in zip(one, ahead))
-    assert [a for a, k in zip(one, "GGMGMMMGG") if k == "M"] == [a for a, k in zip(ahead, "GGMGMMMGG") if k == "M"]
+    assert one == ahead
 
 
 def test_mc_nontemporal_instantiation_matches(ctx, orc, plan, env, monkeypatch):

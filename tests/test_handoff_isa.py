@@ -1,5 +1,5 @@
-"""The cross-workgroup hand-offs of the GMM kernels (partial rows -> last arriver; mixture state and
-sampler parameters -> the next waypoint's tasks; the write-through sample stream of k_gmm_run) rest
+"""The cross-workgroup hand-offs of the GMM kernel (the rows of a run's virtual slices -> the last
+arriver; mixture state and sampler parameters -> the next waypoint's launch) rest
 on properties of the EMITTED gfx950 ISA, which a compiler update could change without a test on the
 GPU noticing for a long time (cdna_hip_programming.md Guideline 16).  This test disassembles the
 code object inside the built libpocs.so offline (llvm-objdump; no GPU needed) and checks the shapes:
@@ -53,8 +53,7 @@ def mem_ops(ops, prefix):
     return [o for o in ops if o.startswith(prefix)]
 
 
-@pytest.mark.parametrize("sub,streaming_bits", [("k_gmm_runILi3ELb1ELi512", "sc1"), ("k_gmm_stepILi3ELb1ELi512", "nt"),
-                                                ("k_gmm_runILi8ELb1ELi512", "sc1")])
+@pytest.mark.parametrize("sub,streaming_bits", [("k_gmm_stepILi3ELb1ELi512", "nt"), ("k_gmm_stepILi8ELb1ELi512", "nt")])
 def test_gmm_kernel_handoff_shapes(listing, sub, streaming_bits):
     ops = kernel(listing, sub)
     stores = mem_ops(ops, "global_store")
@@ -69,7 +68,7 @@ def test_gmm_kernel_handoff_shapes(listing, sub, streaming_bits):
     plain = [o for o in handed if "sc1" not in o.split()]
     # the plain stores: moments[w][r], which leaves through the kernel boundary -- the shard's, and in
     # k_gmm_step once more after the exchange between ranks (exchange_in_tail), the world's
-    assert len(handed) >= 4 and len(plain) == (2 if "k_gmm_step" in sub else 1), handed
+    assert len(handed) >= 4 and len(plain) == 2, handed
     # L1-bypassing loads of partial rows / params / state (at least one site each)
     loads_sc1 = [o for o in mem_ops(ops, "global_load_dwordx2") if "sc1" in o.split()]
     assert len(loads_sc1) >= 3, loads_sc1
@@ -80,8 +79,8 @@ def test_gmm_kernel_handoff_shapes(listing, sub, streaming_bits):
     for i in inv:
         nxt = next(j for j in range(i + 1, len(ops)) if ops[j].startswith(("s_barrier", "s_endpgm")))
         assert any(o.startswith("s_waitcnt") and "vmcnt(0)" in o for o in ops[i + 1:nxt]), (sub, i)
-    # the ticket: a returning agent-scope add behind the drain of the partial row's stores -- and, in
-    # k_gmm_step, behind the barrier at which every wave has drained (in k_gmm_run ONE wave stores and signals)
+    # the ticket: a returning agent-scope add behind the drain of the rows' stores and behind the barrier at
+    # which every wave has drained
     atom = [i for i, o in enumerate(ops) if o.startswith("global_atomic_add")]
     assert atom, "no ticket atomic"
     seen = 0
@@ -92,7 +91,7 @@ def test_gmm_kernel_handoff_shapes(listing, sub, streaming_bits):
         between = ops[prev_store + 1:i]
         if not any(o.startswith("s_waitcnt") and "vmcnt(0)" in o for o in between):
             continue
-        if "k_gmm_step" in sub and not any(o.startswith("s_barrier") for o in between):
+        if not any(o.startswith("s_barrier") for o in between):
             continue
         seen += 1
     assert seen >= 1, "no sc1 store -> s_waitcnt vmcnt(0) [-> s_barrier] -> atomic sequence in " + sub
