@@ -28,6 +28,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+NUMERICS = "v7"                 # counter records of another numerics version describe another kernel
 BYTES_PER_EVAL_GMM = 26         # 3 x f64 sample + i16 flag streamed out once
 BYTES_PER_EVAL_MC = 56          # 24 B in + 24 B out + u32 hit counter read + write
 
@@ -158,37 +159,92 @@ def probe_onehop(par, pocs_amd, torch, dist, rank, world, local):
     """One small sharded GMM call through the library's IPC exchange (pocs_gmm_sample_exchange_local) on
     this node: True if it ran on every rank and every rank got the same probability.  A node where peer
     mapping or in-kernel peer traffic does not work shows here (an exception, or the kernel's bounded wait
-    giving up after 30 s), before anything is timed."""
-    ok, p = 1, -1.0
-    ctx = None
+    giving up after 30 s), before anything is timed.  Every rank issues the SAME sequence of collectives
+    whatever fails where: the ranks agree on ok / failed (an all_reduce of a status word) after the buffers
+    exist, after the handles have gone round, and after the call."""
+    dev = "cuda" if os.environ.get("POCS_DIST_BACKEND", "nccl") == "nccl" else "cpu"
+
+    def agree(ok, extra=()):
+        if dist is None:
+            return bool(ok), list(extra)
+        t = torch.tensor([1.0 if ok else 0.0] + [float(v) for v in extra], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t[0].item()), t[1:].tolist()
+
+    ctx, e, mine, ok = None, None, None, True
     try:
         plan, env = pocs_amd.load_plan(), pocs_amd.load_env()
         ctx = pocs_amd.Context(local)
         ctx.configure(plan, env, K=3, N=8192 * world, seed=0x5EED00AA)
         e = par.GpuEngine(ctx, len(plan["traj"]), 3, 8192 * world, rank=rank, world=world, per_rank=8192, batch=2)
-        e.connect_onehop(dist, rank, world)
-        p = par.run_gmm_onehop_fused([e])[0]
-        torch.cuda.synchronize()
-    except Exception as exc:                           # noqa: BLE001 -- whatever it is, the other path is taken
-        print("one-hop probe: %s" % exc, file=sys.stderr)
-        ok = 0
-    finally:
-        if dist is not None:
-            try:
-                dist.barrier()                         # nobody unmaps a buffer another rank may still be writing to
-            except Exception:                          # noqa: BLE001
-                pass
-        if ctx is not None:
-            try:
-                ctx.close()
-            except Exception:                          # noqa: BLE001
-                pass
-    if dist is not None:
-        t = torch.tensor([float(ok), p, -p], dtype=torch.float64,
-                         device="cuda" if os.environ.get("POCS_DIST_BACKEND", "nccl") == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)       # min ok, min p, -max p
-        ok = int(t[0].item()) and (t[1].item() == -t[2].item())
-    return bool(ok)
+        mine = ctx.xchg_create(world, rank)
+    except Exception as exc:                               # noqa: BLE001
+        print("one-hop probe (setup): %s" % exc, file=sys.stderr)
+        ok = False
+    ok, _ = agree(ok)
+    handles = [mine]
+    if dist is not None and world > 1:                     # every rank takes part, with a placeholder if it has no buffer
+        handles = [None] * world
+        dist.all_gather_object(handles, mine if mine is not None else b"")
+    if ok:
+        try:
+            ctx.xchg_connect(handles)
+        except Exception as exc:                           # noqa: BLE001
+            print("one-hop probe (connect): %s" % exc, file=sys.stderr)
+            ok = False
+    ok, _ = agree(ok)
+    p = -1.0
+    if ok:
+        try:
+            p = par.run_gmm_onehop_fused([e])[0]
+            torch.cuda.synchronize()
+        except Exception as exc:                           # noqa: BLE001 -- whatever it is, the other path is taken
+            print("one-hop probe (call): %s" % exc, file=sys.stderr)
+            ok = False
+    ok, mm = agree(ok, (p, -p))                            # min ok, min p, -max p; also: nobody unmaps a buffer still written to
+    if ctx is not None:
+        try:
+            ctx.close()
+        except Exception:                                  # noqa: BLE001
+            pass
+    return ok and mm[0] == -mm[1]
+
+
+def spawn_ranks(n):
+    """`bench.py --gpus N` started by hand (no RANK / WORLD_SIZE in the environment): bring up the N ranks
+    ourselves -- N fresh child processes of this script, one per GPU, before this process has made any GPU
+    call -- relay rank 0's one JSON line, and fail if any rank fails.  (A launcher such as
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` sets RANK / WORLD_SIZE itself
+    and never gets here.)"""
+    import socket
+    import subprocess
+    forced = os.environ.get("POCS_FORCE_DEVICE")          # rehearsal: every rank on one card (gloo)
+    if forced is None:
+        try:
+            import torch                                   # device_count() does not initialise the GPU on this image
+            have = torch.cuda.device_count()
+        except Exception:                                  # noqa: BLE001
+            have = 0
+        if have < n:
+            print("bench.py: --gpus %d but this node shows %d GPU(s): refusing to print a %d-GPU line from fewer "
+                  "(rehearse the multi-rank path on one card with POCS_FORCE_DEVICE=0 POCS_DIST_BACKEND=gloo)" % (n, have, n),
+                  file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0 inherits stdout (the one JSON line); the other ranks must print nothing there
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        print("bench.py: ranks exited with %s" % rcs, file=sys.stderr)
+        return 1
+    return 0
 
 
 def main():
@@ -211,6 +267,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=float, default=6.0e7, help="size of the CPU baseline sample")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))          # this process never touches the GPU: it starts the ranks and relays
 
     # stdout carries the ONE JSON line and nothing else: libraries that write to fd 1 (RCCL prints
     # a version banner at communicator creation) go to stderr until the line is printed
@@ -343,7 +401,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps([b_hi] * max(1, (args.warmup + batch - 1) // batch) + ([b_lo] if b_lo != b_hi else []))   # >= W untimed steps
+    warm = [b_hi] * max(1, (args.warmup + batch - 1) // batch) + ([b_lo] if b_lo != b_hi else [])          # >= W untimed steps
+    if sharded and path == "gmm" and xmode in ("1", "2"):
+        # the one-hop exchange has passed a small probe; the warm-up is its first run at full size.  Should it fail
+        # there on any rank (the kernel's bounded wait gives up after 30 s and the call returns POCS_E_DEVICE), every
+        # rank switches to the RCCL path for the timed region -- agreed by a collective, so that nobody is left behind.
+        ok = 1.0
+        try:
+            run_steps(warm)
+        except pocs_amd.PocsError as exc:
+            print("rank %d: one-hop exchange failed in the warm-up: %s" % (rank, exc), file=sys.stderr)
+            ok = 0.0
+        if dist is not None:
+            t = torch.tensor([ok], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = t.item()
+        if not ok:
+            xmode, xnote, onehop = "0", "one-hop exchange failed in the warm-up at full size: fell back to RCCL", False
+            run_steps(warm)
+    else:
+        run_steps(warm)
     fence()
     t0 = time.perf_counter()
     prob = run_steps(chunks)
@@ -359,7 +436,7 @@ def main():
     # roofline of the dominant kernel: further calls with the hot kernel bracketed by hipEvents on
     # the launch stream (eager launches; not part of `value`)
     ctx.set_option(pocs_amd.OPT_PROFILE, 1)
-    ms_tot, n_launch = 0.0, 0
+    ms_tot, n_launch, groups, waypoint_us = 0.0, 0, 1, None
     for _ in range(max(1, min(len(chunks), 3))):
         if engines:
             if engines[0].batch != b_hi:
@@ -373,6 +450,9 @@ def main():
         ms, n = ctx.kernel_time()
         ms_tot += ms
         n_launch += n
+        if path == "gmm" and not engines:
+            seq_ms, groups = ctx.sequence_time()
+            waypoint_us = seq_ms * 1e3 / W
     ctx.set_option(pocs_amd.OPT_PROFILE, 0)
     # shader clock under this load, in calls of their own: a sensor read goes through the driver and
     # disturbs the GPU (kernels 15 % slower while it polls), so nothing else is measured meanwhile
@@ -391,36 +471,60 @@ def main():
     kern = "k_gmm_step" if path == "gmm" else ("k_mc_fused" if args.mc_fused else "k_mc_step")
     bpe = BYTES_PER_EVAL_GMM if path == "gmm" else BYTES_PER_EVAL_MC
     avg_ms = ms_tot / max(n_launch, 1)
-    units = n_local * batch                         # evaluations one launch of the hot kernel processes
+    # a call may be issued as G sub-batches whose launches run side by side (POCS_GMM_GROUPS, default 1): the events
+    # bracket sub-batch 0's launches, each of which works on batch / G runs
+    units = n_local * batch // max(groups, 1)       # evaluations one launch of the hot kernel processes
     achieved = (bpe * units) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE
-    # correction applied) are taken offline and committed with their source in profiles/traffic.json
-    traffic, traffic_src = None, None
+    # Committed counter records of this workload (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction applied;
+    # profiles/traffic.json with its sources): HBM bytes and vector instructions per launch.  The record nearest in launch
+    # size is scaled to THIS launch's evaluations -- an extrapolation, said so in `traffic_source`, and dropped (null)
+    # when the nearest record's launch is more than 2 x away.
+    traffic, traffic_src, valu_per_eval, valu_src = None, None, None, None
     tj = ROOT / "profiles" / "traffic.json"
     if tj.exists():
-        # the committed PMC record of this workload whose launch is nearest in size: its measured bytes
-        # per evaluation x the evaluations of THIS launch
         recs = [(k, v) for k, v in json.loads(tj.read_text()).items()
-                if v.get("path", "gmm" if k.startswith("cfg") and not k.startswith("cfg5") else "mc") == path and v.get("evals_per_launch")]
+                if v.get("path", "gmm" if k.startswith("cfg") and not k.startswith("cfg5") else "mc") == path and v.get("evals_per_launch")
+                and v.get("numerics", "v6") == NUMERICS]
         if recs:
             k, rec = min(recs, key=lambda kv: abs(kv[1]["evals_per_launch"] - units))
-            traffic = rec["bytes_per_launch"] / rec["evals_per_launch"] * units
-            traffic_src = "%.3f B/eval measured at %d evals per launch (%s) x %d evals" % (
-                rec["bytes_per_launch"] / rec["evals_per_launch"], rec["evals_per_launch"], rec["source"].split(":")[0], units)
+            if 0.5 <= rec["evals_per_launch"] / units <= 2.0:
+                traffic = rec["bytes_per_launch"] / rec["evals_per_launch"] * units
+                traffic_src = "%.3f B/eval measured at %d evals per launch (%s), scaled to %d evals" % (
+                    rec["bytes_per_launch"] / rec["evals_per_launch"], rec["evals_per_launch"], rec["source"].split(":")[0], units)
+                if rec.get("valu_insts_per_launch"):
+                    valu_per_eval = rec["valu_insts_per_launch"] / (rec["evals_per_launch"] / 64.0)   # wave instructions per wave's 64 evaluations
+                    valu_src = rec["source"].split(":")[0]
     copy_gbps = ctx.copy_bandwidth(1 << 30)       # measured streaming-copy ceiling of this GPU, same process
     fill_gbps = ctx.fill_bandwidth(1 << 30)       # ... and the write-only one (the GMM kernels read nothing)
-    roofline = {"bound": "hbm", "limiter": ("FP64 VALU issue under the board's power cap, not bandwidth: ~180 vector instructions per evaluation "
-                                           "(profiles/r02_*_pmc.txt) keep the SIMDs issuing ~100 % of the time, and the kernel draws the "
-                                           "1.4 kW cap at a shader clock of ~2.0 of 2.4 GHz (`board`, sampled live); the HBM fraction below is what "
-                                           "that arithmetic reaches" if path == "gmm" else "HBM streaming (MC particle state read and written per waypoint)"),
-                "board": board,
+    # What the kernel is actually limited by, in numbers: vector instructions per evaluation (counter record above) x
+    # the evaluations per second inside the kernel, against the chip's wave64 issue rate -- 256 CUs x 4 SIMDs, one vector
+    # instruction per SIMD every 4 cycles -- at the shader clock read live under this load (`board`), or at the peak clock.
+    limiter = None
+    if path == "gmm":
+        clock = (board or {}).get("sclk_MHz") or 2400.0
+        issue_peak = 1024 * clock * 1e6 / 4.0
+        limiter = {"kind": "FP64 vector issue (+ per-lane LDS table reads) at the board's power cap, not HBM bandwidth",
+                   "valu_instr_per_eval": valu_per_eval, "clock_MHz": clock,
+                   "clock_source": "amdgpu hwmon, live" if (board or {}).get("sclk_MHz") else "peak clock (no live reading)",
+                   "valu_issue_frac": (valu_per_eval * (units / 64.0) / (avg_ms * 1e-3) / issue_peak) if (valu_per_eval and avg_ms > 0) else None,
+                   "valu_source": valu_src,
+                   "power_W": (board or {}).get("power_W"), "power_cap_W": (board or {}).get("power_cap_W")}
+    else:
+        limiter = {"kind": "HBM streaming (particle state read and written per waypoint; the hit counter only where a particle collides)"}
+    roofline = {"bound": "hbm", "limiter": limiter, "board": board,
                 "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and avg_ms > 0) else None,
                 "copy_GBps": copy_gbps, "frac_of_copy": achieved / copy_gbps if copy_gbps > 0 else None,
                 "fill_GBps": fill_gbps, "frac_of_fill": achieved / fill_gbps if fill_gbps > 0 else None,
                 "algorithmic_bytes_per_launch": bpe * units, "bytes_per_eval": bpe, "evals_per_launch": units,
-                "avg_kernel_us": avg_ms * 1e3,
+                "avg_kernel_us": avg_ms * 1e3, "concurrent_launches": groups, "waypoint_us": waypoint_us,
                 "evals_per_s_in_kernel": units / (avg_ms * 1e-3) if avg_ms > 0 else 0.0}
+    if dist is not None:                               # every rank's kernel time, so that a scaling run explains itself
+        t = torch.zeros(world, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t[rank] = avg_ms * 1e3
+        dist.all_reduce(t)
+        roofline["ranks_kernel_us"] = {"min": t.min().item(), "max": t.max().item(), "all": t.tolist()}
 
     # one run per call, no batch, no run-ahead: the rate of ONE runGMMEstimation / runSimulation command
     # (SURVEY 8d defines the metric on one run* call; `value` above is the batched throughput)

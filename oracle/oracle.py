@@ -60,11 +60,11 @@ class Oracle:
         self.lib.orc_set_sum_order(C.c_int(1 if order else 0))
 
     # ---- primitives -------------------------------------------------------------------
-    def philox(self, ctr, key):
+    def philox(self, ctr, key, rounds=10):
         c = (C.c_uint32 * 4)(*ctr)
         k = (C.c_uint32 * 2)(*key)
         o = (C.c_uint32 * 4)()
-        self.lib.orc_philox4x32_10(c, k, o)
+        self.lib.orc_philox4x32(c, k, C.c_int(rounds), o)
         return list(o)
 
     def log(self, x):
@@ -137,6 +137,17 @@ class Oracle:
         o = np.zeros(3)
         self.lib.orc_inverse_odometry(_p(p1), _p(p2), _p(o))
         return o
+
+    def generate_M(self, alphas, u):
+        al, u, o = (np.ascontiguousarray(a, np.float64) for a in (alphas, u, np.zeros(3)))
+        self.lib.orc_generate_M(_p(al), _p(u), _p(o))
+        return o
+
+    def applied_control(self, nominal, estimated, goal, control):
+        a, b, c, d = (np.ascontiguousarray(v, np.float64) for v in (nominal, estimated, goal, control))
+        g, ap = np.zeros(3), np.zeros(3)
+        self.lib.orc_applied_control(_p(a), _p(b), _p(c), _p(d), _p(g), _p(ap))
+        return dict(gain=g, applied=ap)
 
     def ekf_predict(self, mu, S, u, Md):
         mu, S, u, Md = (np.ascontiguousarray(a, np.float64) for a in (mu, S, u, Md))

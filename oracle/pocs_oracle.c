@@ -52,10 +52,10 @@
 /* ------------------------------------------------------------------------------------------ */
 /* random streams (build spec "POCS numerics v7")                          */
 /* ------------------------------------------------------------------------------------------ */
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
   uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
   uint32_t k0 = key[0], k1 = key[1];
-  for (int round = 0; round < 10; ++round) {
+  for (int round = 0; round < rounds; ++round) {
     uint64_t prod0 = (uint64_t)c[0] * 0xD2511F53ull;
     uint64_t prod1 = (uint64_t)c[2] * 0xCD9E8D57ull;
     uint32_t hi0 = (uint32_t)(prod0 >> 32), lo0 = (uint32_t)prod0;
@@ -69,6 +69,8 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
   out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
 }
 
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc_philox4x32(ctr, key, 10, out); }
+
 static void draw(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stream, uint32_t slot,
                  uint32_t out[4]) {
   uint32_t ctr[4], key[2];
@@ -78,7 +80,9 @@ static void draw(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stre
   ctr[3] = (stream << 16) | slot;
   key[0] = (uint32_t)(seed & 0xffffffffu);
   key[1] = (uint32_t)(seed >> 32);
-  orc_philox4x32_10(ctr, key, out);
+  /* 10 rounds (Random123's default) everywhere but the mixture samples (stream 3): 7, the generator's
+   * Crush-resistant minimum (Salmon et al., SC'11, table 2) -- build spec, DESIGN.md section 4 */
+  orc_philox4x32(ctr, key, stream == 3 ? 7 : 10, out);
 }
 
 /* natural log of a normal positive double: x = 2^k (1+f), sqrt(.5) < 1+f <= sqrt(2) */
@@ -597,6 +601,22 @@ static double chain_normal(uint64_t seed, int step, int k) {
 
 /* EKF_GaussProp's particle-independent part, MCSimulator.h:692-800.  Per step i < W-1 writes
  * applied[3i..], Mdiag[3i..], noisy[3i..], z[L*i..], mu[3i..], cov[9i..] (any may be NULL). */
+/* generateL (MCSimulator.h:532-553) and the applied control EKF_GaussProp forms from it (:714-726):
+ * gain = diag(ubar_j / (xhat_j != 0 ? xhat_j : 0.1)), ubar = inverseOdometry(estimated, goal) - u*,
+ * xhat = estimated - nominal; applied = u* + gain xhat (the off-diagonal zeros of the 3 x 3 product add
+ * exact zeros).  Pinned against the reference's own text: tests/test_oracle_vs_ref_ekf.py. */
+void orc_applied_control(const double nominal[3], const double estimated[3], const double goal[3],
+                         const double control[3], double gain[3], double applied[3]) {
+  double urequired[3];
+  orc_inverse_odometry(estimated, goal, urequired);                      /* :537 */
+  for (int j = 0; j < 3; ++j) {
+    double xhat = estimated[j] - nominal[j];
+    double ubar = urequired[j] - control[j];
+    gain[j] = ubar / (xhat != 0 ? xhat : 0.1);                           /* :548-550 */
+    applied[j] = control[j] + gain[j] * xhat;                            /* :722-726 */
+  }
+}
+
 int orc_host_chain(const orc_config* cfg, uint64_t seed, double* applied, double* Mdiag,
                    double* noisy, double* z, double* mu_out, double* cov_out) {
   int W = cfg->W, L = cfg->L;
@@ -613,14 +633,8 @@ int orc_host_chain(const orc_config* cfg, uint64_t seed, double* applied, double
     }
     double Md[3];
     orc_generate_M(cfg->alphas, control, Md);                            /* :701 nominal control */
-    double urequired[3], appliedc[3];
-    orc_inverse_odometry(mu, goal, urequired);                           /* generateL :537 */
-    for (int j = 0; j < 3; ++j) {
-      double xhat = mu[j] - nominal[j];
-      double ubar = urequired[j] - control[j];
-      double Ljj = ubar / (xhat != 0 ? xhat : 0.1);                      /* :548-550 */
-      appliedc[j] = control[j] + Ljj * xhat;                             /* :722-726 */
-    }
+    double gain[3], appliedc[3];
+    orc_applied_control(nominal, mu, goal, control, gain, appliedc);     /* generateL :532-553, :714-726 */
     double predMu[3], predSigma[9];
     orc_ekf_predict(mu, cov, appliedc, Md, predMu, predSigma);           /* :746 */
     double a1 = cfg->alphas[0], a2 = cfg->alphas[1], a3 = cfg->alphas[2], a4 = cfg->alphas[3];

@@ -1,7 +1,11 @@
 // mcsimplugin_pocs.cpp -- the OpenRAVE plugin translation unit (drop-in for
 // mcsimplugin/mcsimplugin.cpp): same interface name, same commands, estimator = libpocs.so.
-// NOT built in this repository's image (OpenRAVE and Boost are absent); build it where they are:
+// OpenRAVE and Boost are absent from this repository's image; build the plugin where they are:
 //   g++ -shared -fPIC mcsimplugin_pocs.cpp $(openrave-config --cflags --libs-core) -I../include -lpocs
+// Here the TU is compiled and RUN against tests/openrave_shim/ -- a test double that declares exactly the
+// OpenRAVE / Boost names used below, nothing of OpenRAVE's behaviour -- by tests/plugin_demo.cpp: the three
+// plugin entry points, every command through InterfaceBase::SendCommand, the scene walk on the boxes of
+// pr2test2.env.xml (tests/test_plugin_adapter.py).
 //
 // What the reference's constructor does with `penv` (mcsimplugin.cpp:12 `sim(penv)` ->
 // MCSimulator.h:139-156: keep the environment and its first robot, to be asked
@@ -34,11 +38,12 @@ class MCModule : public ModuleBase {
     const char* ra = getenv("POCS_RUN_AHEAD");
     impl_.SendCommand(std::string("setRunAhead ") + (ra ? ra : "0"));
   }
+  // every command: pocs::MCModule::Forward (csrc/mcmodule.hpp, compiled and tested in this repository) does the
+  // stream handling -- the two estimator commands arrive with NOTHING behind their name -- and the C-ABI call
   bool Forward(const std::string& name, std::ostream& sout, std::istream& sinput) {
-    std::stringstream line;
-    line << name << ' ' << sinput.rdbuf();
-    if (!impl_.SendCommand(sout, line)) { RAVELOG_ERROR("%s: %s\n", name.c_str(), impl_.last_error().c_str()); return false; }
-    return true;
+    if (impl_.Forward(name, sout, sinput)) return true;
+    RAVELOG_ERROR("%s: %s\n", name.c_str(), impl_.last_error().c_str());
+    return false;
   }
 
  private:

@@ -94,16 +94,29 @@ class MCModule {
   const std::string& last_error() const { return err_; }
   pocs_ctx* context() { return ctx_; }
 
- private:
+  // "<name> <rest of sinput>": the line pocs_send_command takes, from a command handler's arguments --
+  // `sinput` is positioned behind the command name and may hold NOTHING more: the reference's two
+  // estimator commands take no tokens (mcsimplugin.cpp:66-81; MCSimulation.py:241,243 sends the bare
+  // names).  The remainder is read character by character: `line << sinput.rdbuf()` would set failbit
+  // on `line` for an exhausted stream (operator<<(streambuf*) inserting no character) and lose the
+  // command.  No GPU in here: tests/mcmodule_demo.cpp checks it on the CPU.
+  static std::string CommandLine(const std::string& name, std::istream& sinput) {
+    const std::string rest((std::istreambuf_iterator<char>(sinput)), std::istreambuf_iterator<char>());
+    return name + " " + rest;
+  }
+
+  // THE handler behind every registered command, and what an OpenRAVE adapter binds its commands to
+  // (plugin/mcsimplugin_pocs.cpp): forwards to pocs_send_command, writes the reply to sout, false on error.
   bool Forward(const std::string& name, std::ostream& sout, std::istream& sinput) {
-    std::string rest((std::istreambuf_iterator<char>(sinput)), std::istreambuf_iterator<char>());
-    const std::string line = name + " " + rest;
+    const std::string line = CommandLine(name, sinput);
     std::vector<char> reply(1 << 16, '\0');
     const int rc = pocs_send_command(ctx_, line.c_str(), reply.data(), reply.size());
     if (rc != POCS_OK) { err_ = pocs_last_error(ctx_); return false; }
     sout << reply.data();
     return true;
   }
+
+ private:
 
   pocs_ctx* ctx_ = nullptr;
   std::map<std::string, std::pair<CommandFn, std::string> > commands_;

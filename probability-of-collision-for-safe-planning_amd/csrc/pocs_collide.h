@@ -73,10 +73,10 @@ POCS_HD bool pocs_box_hit(double px, double py, double sn, double cs, double rx,
 
 // checkCollision for one pose: true if the footprint touches any of the M obstacles.
 POCS_HD bool pocs_pose_collides(double x, double y, double th, const pocs_footprint* fp,
-                                const double* obs, int M, const pocs_tables* T) {
+                                const double* obs, int M, const pocs_tables* T, const pocs_vconst* V = nullptr) {
   if (M <= 0) return false;                     // nothing in reach (k_gmm_step: every obstacle culled): no heading needed
   double sn, cs;
-  pocs_sincos_tab(th, T, &sn, &cs);
+  pocs_sincos_tab(th, T, &sn, &cs, V);
   double px = x, py = y;
   if (!(fp->dx == 0.0 && fp->dy == 0.0)) {      // a centred footprint skips x + (c*0 - s*0) == x
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -612,9 +612,11 @@ int enqueue_ticket_reset(pocs_ctx* c) {
 // How many launches of the hot kernel one whole-run call makes (what POCS_OPT_PROFILE brackets).
 size_t gmm_hot_launches(const pocs_ctx* c) { return (size_t)c->W; }
 
-// Sub-batches of a whole-run call (above): two from 16 runs per call on (each then still fills its half of the
-// resident blocks evenly), one below.  The moment sums do not depend on the launch shape (pocs_kernels.hip,
-// "summation tree"), so the split changes no bit of any result.  POCS_GMM_GROUPS overrides (sweeps: 1..4).
+// Sub-batches of a whole-run call (above).  The moment sums do not depend on the launch shape (pocs_kernels.hip,
+// "summation tree"), so a split changes no bit of any result.  One by default: measured on MI355X (round 3, 10^6
+// samples, K = 3, same box) two sub-batches gave +0.5 % at 20 runs per call and +2.5 % at 64, three and four lost --
+// the launches' tails are mostly blocks of unequal speed, which a second kernel in flight does not fix.
+// POCS_GMM_GROUPS = 1..4 overrides (sweeps; tests/test_gpu_parity.py checks the bits).
 int gmm_groups(const pocs_ctx* c) {
   static int forced = -1;
   if (forced < 0) {
@@ -623,7 +625,7 @@ int gmm_groups(const pocs_ctx* c) {
     if (forced < 0 || forced > 4) forced = 0;
   }
   if (c->ext_moments) return 1;
-  int g = forced ? forced : (c->batch >= 16 ? 2 : 1);
+  int g = forced ? forced : 1;
   if (g > c->batch) g = c->batch;
   return g;
 }

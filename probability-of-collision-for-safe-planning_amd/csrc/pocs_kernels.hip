@@ -79,11 +79,14 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
          (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
 }
 
-// Stage the log / sector tables (12 KB) into LDS.
+// Stage the log / sector tables (12 KB) into LDS.  The log table's 1/c entries are DOUBLED on the way in:
+// the device form of pocs_log_unit32 multiplies them with the mantissa in [1/2, 1) (pocs_math.h).
 __device__ __forceinline__ void stage_tables(const pocs_tables* __restrict__ g, pocs_tables* s_tab) {
   const double* src = reinterpret_cast<const double*>(g);
   double* dst = reinterpret_cast<double*>(s_tab);
-  for (int j = threadIdx.x; j < (int)(sizeof(pocs_tables) / sizeof(double)); j += blockDim.x) dst[j] = src[j];
+  constexpr int NLG = (int)(sizeof(g->lg) / sizeof(double));
+  for (int j = threadIdx.x; j < (int)(sizeof(pocs_tables) / sizeof(double)); j += blockDim.x)
+    dst[j] = (j < NLG && (j & 1) == 0) ? 2.0 * src[j] : src[j];
 }
 
 // The MC kernels only evaluate the footprint heading: the 4 KB sector table is all they need.
@@ -583,6 +586,12 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
   double *xr = nullptr, *yr = nullptr, *tr = nullptr;
   int16_t* fr = nullptr;
   int seg_end = 0;                                  // local sample index up to which (exclusive) the samples belong to component kw and exist
+#if !defined(POCS_NO_VCONST)
+  POCS_VCONST(vc_);                                 // three polynomial constants held in vector registers (pocs_math.h)
+  const pocs_vconst* const vc = &vc_;
+#else
+  const pocs_vconst* const vc = nullptr;
+#endif
 
   // ONE iteration = 2 * TB samples, one pair per thread.  WHOLE (compile time): the wave's 128 samples lie
   // inside component block kw and inside the shard -- every lane live, both samples of its pair exist,
@@ -623,7 +632,7 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(seed_it));
 #endif
-    pocs_normal3_pair(seed_it, pair0 + (uint64_t)(unsigned)lp, (uint32_t)w, POCS_STREAM_GMM, s_tab, zz[0], zz[1], &spare[0], &spare[1]);
+    pocs_normal3_pair(seed_it, pair0 + (uint64_t)(unsigned)lp, (uint32_t)w, POCS_STREAM_GMM, s_tab, zz[0], zz[1], &spare[0], &spare[1], vc);
 #endif
     const int i0 = 2 * lp;
     const bool two = WHOLE || (live && (i0 + 1) < count);  // false only for the last sample of an odd shard
@@ -650,7 +659,7 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
 #if defined(POCS_ABLATE_COLLIDE)
       hits[h] = xs[h] > ts[h];
 #else
-      hits[h] = pocs_pose_collides(xs[h], ys[h], ts[h], &fp, s_keep, nkeep, s_tab);
+      hits[h] = pocs_pose_collides(xs[h], ys[h], ts[h], &fp, s_keep, nkeep, s_tab, vc);
 #endif
     }
 #if defined(POCS_ABLATE_MOMENTS)

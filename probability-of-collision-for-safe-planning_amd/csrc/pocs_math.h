@@ -26,8 +26,13 @@
 #endif
 
 // ----------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
-// SC'11).  Counter = 4 x u32, key = 2 x u32.
+// Philox4x32-R (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+// SC'11).  Counter = 4 x u32, key = 2 x u32.  R = 10 rounds, Random123's default, for the host chain,
+// the initial particle cloud and the component counts; R = 7 for the mixture samples, the stream the
+// hot kernel draws per pair of samples: the paper's own Crush-resistant minimum for Philox4x32 (it passes
+// BigCrush with 7 rounds; 10 is a safety margin), 30 % fewer of the integer multiplies that make up a
+// fifth of the kernel.  Both round counts are pinned by Random123's known-answer vectors
+// (tests/test_oracle_primitives.py).
 // ----------------------------------------------------------------------------------------
 struct pocs_u32x4 { uint32_t x, y, z, w; };
 
@@ -40,10 +45,11 @@ POCS_HD uint32_t pocs_xor3(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 
-POCS_HD pocs_u32x4 pocs_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                      uint32_t k0, uint32_t k1) {
+template <int ROUNDS>
+POCS_HD pocs_u32x4 pocs_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                   uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = pocs_xor3((uint32_t)(p1 >> 32), c1, k0);
@@ -64,10 +70,18 @@ POCS_HD pocs_u32x4 pocs_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uin
 #define POCS_STREAM_MCINIT 2u  // initial particle cloud                   (MCSimulator.h:287-297)
 #define POCS_STREAM_GMM 3u     // mixture samples                          (GM_Model.h:83-116)
 
+POCS_HD pocs_u32x4 pocs_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  return pocs_philox4x32<10>(c0, c1, c2, c3, k0, k1);
+}
+#define POCS_GMM_PHILOX_ROUNDS 7
+
 POCS_HD pocs_u32x4 pocs_draw(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stream,
                              uint32_t slot) {
-  return pocs_philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), waypoint,
-                            (stream << 16) | slot, (uint32_t)seed, (uint32_t)(seed >> 32));
+  if (stream == POCS_STREAM_GMM)          // (a literal at every call site: one of the two is compiled)
+    return pocs_philox4x32<POCS_GMM_PHILOX_ROUNDS>((uint32_t)index, (uint32_t)(index >> 32), waypoint,
+                                                   (stream << 16) | slot, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return pocs_philox4x32<10>((uint32_t)index, (uint32_t)(index >> 32), waypoint,
+                             (stream << 16) | slot, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
 // ----------------------------------------------------------------------------------------
@@ -178,6 +192,19 @@ struct pocs_tables {
   double sc[256][2];
 };
 
+// The first Horner step of each of the three polynomials below multiplies by one literal and adds another; a
+// gfx950 VALU instruction reads at most one literal / scalar operand, so one of the two needs a register and
+// the compiler materialises it with a v_mov_b64 EVERY time (13 per pair of samples).  The hot kernel keeps
+// the three addends in vector registers for the length of its loop instead (POCS_VCONST pins them there);
+// same values, same operations.  Everyone else passes nullptr and gets the literals.
+struct pocs_vconst { double log_c4, sin_c3, cos_c4; };    // -1/4, -1/6, 1/24
+#if defined(__HIP_DEVICE_COMPILE__)
+#define POCS_VCONST(name) pocs_vconst name = {-1.0 / 4.0, -1.0 / 6.0, 1.0 / 24.0}; \
+  asm volatile("" : "+v"(name.log_c4), "+v"(name.sin_c3), "+v"(name.cos_c4))
+#else
+#define POCS_VCONST(name) pocs_vconst name = {-1.0 / 4.0, -1.0 / 6.0, 1.0 / 24.0}
+#endif
+
 POCS_HD void pocs_tables_init(pocs_tables* T) {
   for (int i = 0; i < 512; ++i) {
     const double c = 1.0 + ((double)i + 0.5) * 0x1p-9;
@@ -197,37 +224,52 @@ POCS_HD void pocs_tables_init(pocs_tables* T) {
 // m = w + 1 = 2^e t, t in [1,2); i = top 9 mantissa bits; r = t*invc_i - 1 (one fma,
 // |r| < 2^-9.9); log = (e-32) ln2 + logc_i + log1p(r), log1p by its degree-5 Taylor polynomial
 // (truncation < 2^-62 absolute).
-POCS_HD double pocs_log_unit32(uint32_t w, const pocs_tables* T) {
+POCS_HD double pocs_log_unit32(uint32_t w, const pocs_tables* T, const pocs_vconst* V = nullptr) {
   union { double d; uint64_t u; } b; b.d = (double)w + 1.0;      // exact: m <= 2^32
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The same quantities with fewer instructions.  m = 2^e t = 2^(e+1) mant with mant = t / 2 in [1/2, 1): the
+  // hardware's frexp gives mant and e + 1 in one instruction each; the table entry's byte offset is a shift
+  // and a mask of the high word; and r = fma(t, invc, -1) = fma(mant, 2 invc, -1) exactly, for which the
+  // kernel's LDS copy of the table holds 2 invc (stage_tables doubles the entry on its way in: exact).
+  const int e1 = __builtin_amdgcn_frexp_exp(b.d);                 // e + 1
+  const double mant = __builtin_amdgcn_frexp_mant(b.d);
+  const unsigned off = ((unsigned)(b.u >> 32) >> 7) & 0x1ff0u;    // 16 i
+  const double* ent = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&T->lg[0][0]) + off);
+  const double r = fma(mant, ent[0], -1.0);
+  const double logc = ent[1];
+  const double dk = (double)(e1 - 33);
+#else
   const int e = (int)(b.u >> 52) - 1023;
   const int i = (int)(b.u >> 43) & 511;
   b.u = (b.u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;   // t
   const double r = fma(b.d, T->lg[i][0], -1.0);
-  double p = fma(r, 1.0 / 5.0, -1.0 / 4.0);
+  const double logc = T->lg[i][1];
+  const double dk = (double)(e - 32);
+#endif
+  double p = fma(r, 1.0 / 5.0, V ? V->log_c4 : -1.0 / 4.0);
   p = fma(r, p, 1.0 / 3.0);
   p = fma(r, p, -0.5);
   p = fma(r * r, p, r);                                           // log1p(r)
-  const double dk = (double)(e - 32);
-  return fma(dk, 6.93147180369123816490e-01, T->lg[i][1]) + fma(dk, 1.90821492927058770002e-10, p);
+  return fma(dk, 6.93147180369123816490e-01, logc) + fma(dk, 1.90821492927058770002e-10, p);
 }
 
 // sin / cos of a small angle |d| <= pi/256 (Taylor to d^5 / d^6: truncation < 1e-17)
-POCS_HD void pocs_sincos_small(double d, double* sd, double* cd) {
+POCS_HD void pocs_sincos_small(double d, double* sd, double* cd, const pocs_vconst* V = nullptr) {
   const double z = d * d;
-  const double ps = fma(z, 1.0 / 120.0, -1.0 / 6.0);
+  const double ps = fma(z, 1.0 / 120.0, V ? V->sin_c3 : -1.0 / 6.0);
   *sd = fma(d * z, ps, d);
-  double pc = fma(z, -1.0 / 720.0, 1.0 / 24.0);
+  double pc = fma(z, -1.0 / 720.0, V ? V->cos_c4 : 1.0 / 24.0);
   pc = fma(z, pc, -0.5);
   *cd = fma(z, pc, 1.0);
 }
 
 // sin and cos of 2 pi w 2^-32: sector = top 8 bits, d = offset from the sector centre.
-POCS_HD void pocs_sincos_2pi_u32_tab(uint32_t w, const pocs_tables* T, double* sn, double* cs) {
+POCS_HD void pocs_sincos_2pi_u32_tab(uint32_t w, const pocs_tables* T, double* sn, double* cs, const pocs_vconst* V = nullptr) {
   const int s = (int)(w >> 24);
   const int f = (int)(w & 0x00ffffffu) - (1 << 23);                       // [-2^23, 2^23)
   const double d = (double)f * (0x1p-24 * 2.45436926061702587187e-02);    // 2 pi / 256 per sector
   double sd, cd;
-  pocs_sincos_small(d, &sd, &cd);
+  pocs_sincos_small(d, &sd, &cd, V);
   const double C = T->sc[s][0], S = T->sc[s][1];
   *sn = fma(S, cd, C * sd);
   *cs = fma(C, cd, -(S * sd));
@@ -236,7 +278,7 @@ POCS_HD void pocs_sincos_2pi_u32_tab(uint32_t w, const pocs_tables* T, double* s
 // sin and cos of an arbitrary angle |x| < 2^18 by the same sectors: n = floor(x * 256/(2 pi)),
 // d = x - n * (2 pi / 256) in three Cody-Waite steps (33 + 33 + 53 bit split of pi/128), then the
 // offset from the centre of sector n mod 256.
-POCS_HD void pocs_sincos_tab(double x, const pocs_tables* T, double* sn, double* cs) {
+POCS_HD void pocs_sincos_tab(double x, const pocs_tables* T, double* sn, double* cs, const pocs_vconst* V = nullptr) {
   const double fn = floor(x * 4.07436654315252084757e+01);
   const int n = (int)fn;
   double d = fma(-fn, 2.45436926052207127213e-02, x);    // pi/128, first 33 bits (fn * it is exact)
@@ -244,7 +286,7 @@ POCS_HD void pocs_sincos_tab(double x, const pocs_tables* T, double* sn, double*
   d = fma(-fn, 3.15979101374367286178e-23, d);           // tail
   // sector centres sit at (s + 1/2) * pi/128: shift by half a sector
   double sd, cd;
-  pocs_sincos_small(d - 1.22718463030851293594e-02, &sd, &cd);
+  pocs_sincos_small(d - 1.22718463030851293594e-02, &sd, &cd, V);
   const int s = n & 255;
   const double C = T->sc[s][0], S = T->sc[s][1];
   *sn = fma(S, cd, C * sd);
@@ -290,12 +332,12 @@ POCS_HD double pocs_sqrt_radius2(double t) {
 // Box-Muller pair of the mixture sampler, through the tables: one word for the radius,
 // u = (wr + 1) 2^-32 in (0,1], radius = sqrt(-2 log u) <= sqrt(64 ln 2) < 6.661 (the bound the
 // obstacle culling of k_gmm_step relies on), one word for the angle 2 pi wa 2^-32.
-POCS_HD void pocs_normal_pair_w2(uint32_t wr, uint32_t wa, const pocs_tables* T, double* n0, double* n1) {
+POCS_HD void pocs_normal_pair_w2(uint32_t wr, uint32_t wa, const pocs_tables* T, double* n0, double* n1, const pocs_vconst* V = nullptr) {
   // |.|: at u = 1 (wr = 2^32 - 1) the table form of log may land a rounding error (1e-19) ABOVE
   // zero; the radius is then ~1e-9 instead of 0, never the square root of a negative number
-  const double rad = pocs_sqrt_radius2(fabs(-2.0 * pocs_log_unit32(wr, T)));
+  const double rad = pocs_sqrt_radius2(fabs(-2.0 * pocs_log_unit32(wr, T, V)));
   double sn, cs;
-  pocs_sincos_2pi_u32_tab(wa, T, &sn, &cs);
+  pocs_sincos_2pi_u32_tab(wa, T, &sn, &cs, V);
   *n0 = rad * cs;
   *n1 = rad * sn;
 }
@@ -306,12 +348,12 @@ POCS_HD void pocs_normal_pair_w2(uint32_t wr, uint32_t wa, const pocs_tables* T,
 //   slot 1: (x, y) -> z1, z2 of sample 2j+1    z, w  -> the spare words of samples 2j, 2j+1
 POCS_HD void pocs_normal3_pair(uint64_t seed, uint64_t pair, uint32_t waypoint, uint32_t stream,
                                const pocs_tables* T, double za[3], double zb[3], uint32_t* spare_a,
-                               uint32_t* spare_b) {
+                               uint32_t* spare_b, const pocs_vconst* V = nullptr) {
   const pocs_u32x4 a = pocs_draw(seed, pair, waypoint, stream, 0u);
   const pocs_u32x4 b = pocs_draw(seed, pair, waypoint, stream, 1u);
-  pocs_normal_pair_w2(a.x, a.y, T, &za[0], &za[1]);
-  pocs_normal_pair_w2(a.z, a.w, T, &za[2], &zb[0]);
-  pocs_normal_pair_w2(b.x, b.y, T, &zb[1], &zb[2]);
+  pocs_normal_pair_w2(a.x, a.y, T, &za[0], &za[1], V);
+  pocs_normal_pair_w2(a.z, a.w, T, &za[2], &zb[0], V);
+  pocs_normal_pair_w2(b.x, b.y, T, &zb[1], &zb[2], V);
   *spare_a = b.z;
   *spare_b = b.w;
 }

@@ -22,6 +22,10 @@ void hh_philox(const uint32_t* c, const uint32_t* k, uint32_t* o) {
   pocs_u32x4 r = pocs_philox4x32_10(c[0], c[1], c[2], c[3], k[0], k[1]);
   o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
 }
+void hh_philox7(const uint32_t* c, const uint32_t* k, uint32_t* o) {
+  pocs_u32x4 r = pocs_philox4x32<7>(c[0], c[1], c[2], c[3], k[0], k[1]);
+  o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+}
 double hh_log(double x) { return pocs_log(x); }
 void hh_sincos(double x, double* s, double* c) { pocs_sincos(x, s, c); }
 void hh_sincos_2pi_u32(uint32_t w, double* s, double* c) { pocs_sincos_2pi_u32(w, s, c); }

@@ -32,12 +32,26 @@ def test_default_line_has_every_field():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert r["algorithmic_bytes_per_launch"] == 26 * r["evals_per_launch"]
-    assert r["traffic"] is not None and r["traffic"] > 0 and "B/eval measured" in r["traffic_source"]      # never null
-    assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    # 100 000 evaluations per launch here: no committed counter record within 2 x of that -> no extrapolated traffic
+    assert r["traffic"] is None and r["traffic_source"] is None
+    assert r["limiter"]["kind"].startswith("FP64") and r["concurrent_launches"] == 1 and r["waypoint_us"] > 0
     assert d["single_call_evals_per_s"] > 0 and "single_call" in d["config"]["value_is"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 0 and abs(d["value"] - 20000 * 56 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-9
+
+
+def test_full_size_line_carries_the_counter_records():
+    """At the workload's own size the line carries the committed PMC figures: HBM bytes per launch (close to the
+    algorithmic 26 B/eval) and the vector instructions per evaluation with the issue fraction they imply."""
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                         capture_output=True, text=True, check=True, cwd=str(ROOT))
+    d = json.loads(out.stdout.splitlines()[-1])
+    r = d["roofline"]
+    assert r["evals_per_launch"] == 20_000_000 and r["traffic"] is not None and "measured at" in r["traffic_source"]
+    assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    lim = r["limiter"]
+    assert 100 < lim["valu_instr_per_eval"] < 200 and 0.3 < lim["valu_issue_frac"] < 1.0 and lim["clock_MHz"] > 1000
 
 
 def test_strong_scaling_line():
@@ -59,6 +73,22 @@ def test_sharded_path_on_one_rank_prints_one_line():
                WORLD_SIZE="1", LOCAL_RANK="0")
     d = run_bench("--no-cpu-baseline", env=env)
     assert d["n_gpus"] == 1 and d["value"] > 0 and sum(d["config"]["calls"]) == 5
+
+
+def test_gpus_2_started_by_hand_brings_up_its_own_ranks():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment: the parent starts the two ranks
+    itself (here both on the one card, gloo as the host channel), relays rank 0's ONE line, and that line says
+    n_gpus 2 -- never a 1-GPU line for a 2-GPU request.  Without enough GPUs and without the rehearsal switch it
+    refuses."""
+    import os
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = run_bench("--gpus", "2", "--no-cpu-baseline", env=dict(env, POCS_FORCE_DEVICE="0", POCS_DIST_BACKEND="gloo",
+                                                                POCS_SKIP_SINGLE="1", POCS_NO_BOARD_PROBE="1"))
+    assert d["n_gpus"] == 2 and d["config"]["total_samples_per_run"] == 40000 and "tail" in d["config"]["exchange"]
+    assert len(d["roofline"]["ranks_kernel_us"]["all"]) == 2
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, cwd=str(ROOT), env=env)
+    assert out.returncode != 0 and out.stdout.strip() == "" and "refusing" in out.stderr
 
 
 def test_two_ranks_on_one_card_take_the_onehop_path():

@@ -16,9 +16,20 @@ def ulp_diff(a, b):
     return abs(a - b) / max(math.ulp(b), 5e-324)
 
 
+# ... and for philox4x32-7 (same file of the Random123 distribution): the round count of the mixture-sample stream
+PHILOX7_KAT = [
+    ([0, 0, 0, 0], [0, 0], [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]),
+]
+
+
 def test_philox_known_answers(orc):
     for ctr, key, want in PHILOX_KAT:
         assert orc.philox(ctr, key) == want
+    for ctr, key, want in PHILOX7_KAT:
+        assert orc.philox(ctr, key, rounds=7) == want
 
 
 def test_log_within_one_ulp(orc):

@@ -17,6 +17,8 @@ def test_philox_bitwise(hh, orc):
         o = (C.c_uint32 * 4)()
         hh.hh_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), o)
         assert list(o) == orc.philox(ctr, key)
+        hh.hh_philox7((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), o)
+        assert list(o) == orc.philox(ctr, key, rounds=7)
 
 
 def test_math_bitwise(hh, orc):
