@@ -450,7 +450,7 @@ def main():
         ms, n = ctx.kernel_time()
         ms_tot += ms
         n_launch += n
-        if path == "gmm" and not engines:
+        if path == "gmm" and not engines and hasattr(ctx.lib, "pocs_get_sequence_time"):      # (an A/B library of an older commit has none)
             seq_ms, groups = ctx.sequence_time()
             waypoint_us = seq_ms * 1e3 / W
     ctx.set_option(pocs_amd.OPT_PROFILE, 0)

@@ -798,11 +798,14 @@ __device__ __forceinline__ void gmm_emit_rows(const pocs_gmm_launch& a, gmm_smem
     double v = 0.0;
     if (col != 1) {
       const int s = col == 0 ? 0 : col - 1;
+      // the eight waves' terms are fetched side by side (both candidates of each: one LDS round trip), then added in wave order
+      double ps[NW], px[NW];
+      int kf[NW], xj[NW];
+#pragma unroll
+      for (int u = 0; u < NW; ++u) { kf[u] = sm.kf[tl][u]; xj[u] = sm.xj[rb][u][k]; ps[u] = sm.slot[tl][u][s]; px[u] = sm.xtra[rb][u][k][s]; }
 #pragma unroll
       for (int u = 0; u < NW; ++u) {
-        double p = 0.0;
-        if (sm.kf[tl][u] == k) p = sm.slot[tl][u][s];
-        else if (sm.xj[rb][u][k] == tl) p = sm.xtra[rb][u][k][s];
+        const double p = kf[u] == k ? ps[u] : (xj[u] == tl ? px[u] : 0.0);
         v = (u == 0) ? p : v + p;
       }
     }
@@ -927,9 +930,11 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   if (tid == 0 && r1 == r0) sm.last[1] = 0;
   __syncthreads();
   POCS_STAMP(4);
-#pragma nounroll
-  for (int rb = 0; rb <= r1 - r0; ++rb) {
-    if (__builtin_amdgcn_readfirstlane(sm.last[rb]) == 0) continue;
+  // The closer of a run, written out for the block's first run and -- when its range crosses into a second one --
+  // once more, NOT as a loop over the two: the advance wants every vector register there is, and in a loop
+  // whatever the compiler hoists out of the body (thread-dependent addresses) is live across it and spilled
+  // (256 bytes of scratch per lane instead of 60).
+  auto closer = [&](const int rb) __attribute__((always_inline)) -> bool {
     const int r = r0 + rb;
     if (tid == 0) acquire_agent();
     __syncthreads();
@@ -940,8 +945,8 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
       // sharded: the run's closer is also its messenger -- this shard's moments go to every rank, the world's
       // come back summed in rank order, and the mixture advances here (no launch, no host, between waypoints)
       __syncthreads();
-      if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-      if (!gmm_exchange_rows(a, a.xchg, K, w, r, l_mom, l_mom, tid, TB, &sm.nkeep[0] /* free by now */)) return;
+      if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      if (!gmm_exchange_rows(a, a.xchg, K, w, r, l_mom, l_mom, tid, TB, &sm.nkeep[0] /* free by now */)) return false;
     }
     if (a.advance_in_tail) advance_block(a, K, w + 1, r, sm.adv(), sm.spec(), true, tid, TB);     // starts with a barrier after staging
     __syncthreads();
@@ -949,7 +954,11 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
 #if defined(POCS_STAMPS)
     if (tid == 0) atomicAdd(&g_stamps[14], 1ull);
 #endif
-  }
+    return true;
+  };
+  const int last0 = __builtin_amdgcn_readfirstlane(sm.last[0]), last1 = __builtin_amdgcn_readfirstlane(sm.last[1]);
+  if (last0 && !closer(0)) return;
+  if (last1) (void)closer(1);
 }
 
 // MC kernels: blockIdx.y = run of the batch (its own seed, its own noisy controls, its own slice

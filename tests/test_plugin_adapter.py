@@ -39,7 +39,7 @@ def test_adapter_runs_every_reference_command(demo, orc, plan, env):
                          capture_output=True, text=True, check=True)
     res = dict(ln.split(None, 1) for ln in out.stdout.strip().splitlines())
     assert res["ADVERTISED"] == "MCModule" and res["MYCOMMAND"] == "output"
-    assert res["COMMANDS"] == "19 of 19"
+    assert res["COMMANDS"] == "18 of 18"
     cfg = orc.config(plan, env, K=3)
     # the scene walked from the (shim) environment is the table of data/pr2test2_env.txt: same answers
     assert float(res["GMM"]) == orc.run_gmm(cfg, 99, 3000)["prob"]
