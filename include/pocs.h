@@ -77,13 +77,13 @@ int pocs_send_command(pocs_ctx* ctx, const char* line, char* out, size_t cap);
                                       With one run per call (batch 1), a run* call evaluates the NEXT R
                                       runs of the context in one launch and the following R-1 calls are served from it -- the
                                       reference driver's one-command-per-run loop (MCSimulation.py:238-256) at batch throughput.
-                                      Same runs, same seeds, same results and getters as one launch per run; any setter ends the
+                                      Same runs, same seeds, and -- the moment sums being defined on a run's virtual slices, not on
+                                      the launch -- bit for bit the same results and getters as one launch per run
+                                      (tests/test_gpu_parity.py::test_timed_launch_shapes_against_the_oracle); any setter ends the
                                       serving and the run counter resumes after the last run handed out.  Text: setRunAhead R */
-#define POCS_OPT_PERSISTENT 6      /* 0 (default): one launch per waypoint (k_gmm_step + in-tail mixture advance);
-                                      1: the whole call -- all W waypoints of all its runs -- is ONE queue-driven launch (k_gmm_run:
-                                      per-run `ready` words instead of launch boundaries).  Same tasks, same arithmetic, bitwise
-                                      the same results; on MI355X the per-waypoint form is as fast from 64 runs per call and
-                                      faster below, hence the default. */
+#define POCS_OPT_PERSISTENT 6      /* retired (round 3): 0 is accepted, 1 returns POCS_E_ARG.  Round 2's queue-driven whole-call kernel
+                                      (k_gmm_run) was slower than one launch per waypoint at every batch size measured and is gone
+                                      (DESIGN.md section 5). */
 int pocs_set_option(pocs_ctx* ctx, int option, long long value);
 
 /* ---- batches of independent runs (ours) --------------------------------------------------
@@ -91,7 +91,8 @@ int pocs_set_option(pocs_ctx* ctx, int option, long long value);
  * (MCSimulation.py:238-256).  With a batch of R, one pocs_run_gmm_estimation / begin..end
  * sequence advances R independent estimations in lockstep (one launch per waypoint for all of
  * them); run i of the batch draws exactly what the i-th of R consecutive single runs would have
- * drawn.  pocs_run_gmm_estimation returns run 0's probability, pocs_get_batch_probabilities all
+ * drawn -- and computes, bit for bit, what it would have computed: the launch shape changes no result.
+ * pocs_run_gmm_estimation returns run 0's probability, pocs_get_batch_probabilities all
  * R.  The per-waypoint exchange of the step API then covers R x 11K doubles.  runSimulation is
  * batched the same way (pocs_mc_get_batch_counts: the shard's collided particles per run). */
 int pocs_set_batch(pocs_ctx* ctx, int runs);
@@ -128,11 +129,19 @@ int pocs_gmm_end(pocs_ctx* ctx, double* probability);
  * mixture of waypoint w+1, so the sequence per waypoint is sample_local(w), exchange_local(w) -- no
  * advance_local, no all-reduce.  Setup, once: pocs_xchg_create on every rank (returns the 64-byte IPC
  * handle of its buffer), the caller gathers the handles (any host channel), pocs_xchg_connect(handles of
- * rank 0 .. world-1, 64 bytes each).  world <= 8, batch <= 256. */
+ * rank 0 .. world-1, 64 bytes each).  world <= 8, batch <= 256.
+ * Two rules for connected contexts: (1) LOCK STEP -- every rank calls pocs_gmm_begin the same number of times
+ * and exchanges the same waypoints in the same order: the count of begin..end sequences is part of every row's
+ * epoch and of the choice between the two slot sets; (2) NOBODY LEAVES EARLY -- a rank must not destroy its
+ * context (or exit) while a peer may still write into or read from its buffer: put a barrier of the host
+ * channel between the last pocs_gmm_end and pocs_destroy, as bench.py and the tests do.
+ * A peer that never arrives makes the kernel's bounded wait (30 s, once per call) give up: pocs_gmm_end then
+ * returns POCS_E_DEVICE and the call's results are discarded. */
 int pocs_xchg_create(pocs_ctx* ctx, int world, int rank, void* handle64_out);
 int pocs_xchg_connect(pocs_ctx* ctx, const void* handles_world_x_64, int world);
 int pocs_gmm_exchange_local(pocs_ctx* ctx, int waypoint);
-/* The two in ONE launch (the form bench.py uses with POCS_ONEHOP=1): the block that closes a run's
+/* The two in ONE launch (what bench.py uses for N > 1 by default, POCS_ONEHOP=2, after a probe of it on the node;
+ * POCS_ONEHOP=1 is the two-launch form above, POCS_ONEHOP=0 one RCCL all-reduce per waypoint): the block that closes a run's
  * waypoint is also its messenger -- it sends the shard's moments, waits for the world's, adds them in rank
  * order and builds the next mixture, while the launch's finished blocks have already given their CUs to
  * whatever else is queued (a second context's sampling launch).  Per waypoint: sample_exchange_local(w);

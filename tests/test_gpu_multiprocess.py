@@ -78,9 +78,33 @@ def _worker_onehop(rank, world, port, n_local, K, seed, batch, out):
         res[mode] = (list(e.probabilities()), np.array([c.moments(w, K) for w in range(56)]))
         dist.barrier()
         c.close()
+    # an ODD number of waypoints, two calls on the same connected buffers: the last exchange of the first call and
+    # the first of the second must not share a slot set (slots alternate with a running exchange count, not with
+    # the waypoint's parity)
+    odd = dict(traj=plan["traj"][:21], odom=plan["odom"][:20])
+    for mode in ("gloo_odd", "fused_odd", "onehop_odd"):
+        c = pocs_amd.Context(0)
+        c.configure(odd, env, K=K, N=N, seed=seed)
+        e = par.GpuEngine(c, 21, K, N, rank=rank, world=world, per_rank=n_local, batch=batch, stream=torch.cuda.Stream())
+        if mode != "gloo_odd":
+            e.connect_onehop(dist, rank, world)
+        both = []
+        for call in range(3):
+            if mode == "gloo_odd":
+                par.run_gmm_pipelined([e], dist)
+            elif mode == "fused_odd":
+                par.run_gmm_onehop_fused([e])
+            else:
+                par.run_gmm_onehop([e])
+            torch.cuda.synchronize()
+            both += list(e.probabilities())
+        res[mode] = both
+        dist.barrier()
+        c.close()
     if rank == 0:
         np.savez(out, p_gloo=res["gloo"][0], p_one=res["onehop"][0], m_gloo=res["gloo"][1], m_one=res["onehop"][1],
-                 p_again=res["onehop_again"][0], p_fused=res["fused"][0], m_fused=res["fused"][1])
+                 p_again=res["onehop_again"][0], p_fused=res["fused"][0], m_fused=res["fused"][1],
+                 odd_gloo=res["gloo_odd"], odd_fused=res["fused_odd"], odd_onehop=res["onehop_odd"])
     dist.destroy_process_group()
 
 
@@ -99,6 +123,9 @@ def test_onehop_exchange_equals_the_collective(tmp_path, pocs, plan, env):
     assert list(got["p_again"]) != list(got["p_one"]) and all(0 < p < 1 for p in got["p_again"])
     # the exchange in the sampling launch's tail: the same bits again
     assert list(got["p_fused"]) == list(got["p_gloo"]) and np.array_equal(got["m_fused"], got["m_gloo"])
+    # 21 waypoints, three calls in a row on the same buffers: every call of both one-hop forms equals the collective's
+    assert list(got["odd_fused"]) == list(got["odd_gloo"]) and list(got["odd_onehop"]) == list(got["odd_gloo"])
+    assert len(set(got["odd_gloo"])) == len(got["odd_gloo"])
     with pocs.Context(0) as c:                              # and both equal one process on the whole mixture
         c.configure(plan, env, K=K, N=2 * n_local, seed=seed)
         c.set_batch(batch)
