@@ -92,6 +92,39 @@ POCS_HD bool pocs_pose_collides(double x, double y, double th, const pocs_footpr
   return hit;
 }
 
+// The same predicate for the two poses a thread of k_gmm_step draws per iteration, with ONE pass over the obstacle
+// table: every record is read once for both poses (the table sits in LDS), the loop's bookkeeping is paid once.
+// Per pose exactly the operations of pocs_pose_collides, in the same order: the same flags.
+POCS_HD void pocs_pair_collides(const double x[2], const double y[2], const double th[2], const pocs_footprint* fp,
+                                const double* obs, int M, const pocs_tables* T, const pocs_vconst* V, bool hit[2]) {
+  hit[0] = false; hit[1] = false;
+  if (M <= 0) return;
+  double sn[2], cs[2], px[2], py[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int h = 0; h < 2; ++h) {
+    pocs_sincos_tab(th[h], T, &sn[h], &cs[h], V);
+    px[h] = x[h]; py[h] = y[h];
+  }
+  if (!(fp->dx == 0.0 && fp->dy == 0.0)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("; offset footprint");
+#endif
+    for (int h = 0; h < 2; ++h) {
+      px[h] = x[h] + fma(cs[h], fp->dx, -(sn[h] * fp->dy));
+      py[h] = y[h] + fma(sn[h], fp->dx, cs[h] * fp->dy);
+    }
+  }
+  for (int m = 0; m < M; ++m) {
+    const double* o = obs + m * POCS_OBS_STRIDE;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int h = 0; h < 2; ++h) hit[h] = hit[h] | pocs_box_hit(px[h], py[h], sn[h], cs[h], fp->hx, fp->hy, o);
+  }
+}
+
 // The footprint's largest half-extent along world x over all headings in [lo, hi] (along world y: the
 // same function of [lo - pi/2, hi - pi/2]): an upper bound, never more than the bounding radius.
 //   f(t) = rx |cos t| + ry |sin t| is concave between the multiples of pi/2 and peaks with the bounding

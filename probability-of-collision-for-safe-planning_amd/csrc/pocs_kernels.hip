@@ -656,12 +656,12 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
       ys[h] = fma(p[5], zz[h][1], fma(p[4], zz[h][0], p[1]));
       ts[h] = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
       ks[h] = k;
-#if defined(POCS_ABLATE_COLLIDE)
-      hits[h] = xs[h] > ts[h];
-#else
-      hits[h] = pocs_pose_collides(xs[h], ys[h], ts[h], &fp, s_keep, nkeep, s_tab, vc);
-#endif
     }
+#if defined(POCS_ABLATE_COLLIDE)
+    hits[0] = xs[0] > ts[0]; hits[1] = xs[1] > ts[1];
+#else
+    pocs_pair_collides(xs, ys, ts, &fp, s_keep, nkeep, s_tab, vc, hits);
+#endif
 #if defined(POCS_ABLATE_MOMENTS)
     acc[1] += xs[0] + ys[0] + ts[0] + xs[1]; nfree += (hits[0] || (two && ks[1] == 0)) ? 0 : 1;
 #else
