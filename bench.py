@@ -370,6 +370,10 @@ def main():
         # one rank per GPU: two engines on two streams take the calls in turn, so one engine's
         # kernel runs while the other's moments are in the all-reduce (parallel.run_gmm_pipelined)
         n_eng = 2 if (path == "gmm" and len(chunks) >= 2 and not fused_exchange) else 1
+        if fused_exchange and path == "gmm" and len(chunks) >= 2 and os.environ.get("POCS_ENGINES") == "2":
+            # skew tolerance: a second batch of runs in flight on a stream of its own -- while one
+            # engine's closers wait for the slowest rank's moments, the other engine's sampling blocks have the chip
+            n_eng = 2
         made = [make(b_hi, 0x5EED0001 + i, torch.cuda.Stream() if n_eng > 1 else None) for i in range(n_eng)]
         ctx = made[0][0]
         engines = [e for _, e in made]

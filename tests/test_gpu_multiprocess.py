@@ -78,6 +78,25 @@ def _worker_onehop(rank, world, port, n_local, K, seed, batch, out):
         res[mode] = (list(e.probabilities()), np.array([c.moments(w, K) for w in range(56)]))
         dist.barrier()
         c.close()
+    # skew tolerance: TWO engines (two batches of runs, two streams, two exchange buffers) in flight through the in-tail
+    # exchange, against the same two batches through the collective
+    pair = {}
+    for mode in ("gloo2", "fused2"):
+        cs, es = [], []
+        for i in range(2):
+            c = pocs_amd.Context(0)
+            c.configure(plan, env, K=K, N=N, seed=seed + 10 + i)
+            e = par.GpuEngine(c, 56, K, N, rank=rank, world=world, per_rank=n_local, batch=batch, stream=torch.cuda.Stream())
+            if mode == "fused2":
+                e.connect_onehop(dist, rank, world)
+            cs.append(c); es.append(e)
+        (par.run_gmm_pipelined(es, dist) if mode == "gloo2" else par.run_gmm_onehop_fused(es))
+        torch.cuda.synchronize()
+        pair[mode] = list(es[0].probabilities()) + list(es[1].probabilities())
+        dist.barrier()
+        for c in cs:
+            c.close()
+    res["gloo2"], res["fused2"] = pair["gloo2"], pair["fused2"]
     # an ODD number of waypoints, two calls on the same connected buffers: the last exchange of the first call and
     # the first of the second must not share a slot set (slots alternate with a running exchange count, not with
     # the waypoint's parity)
@@ -104,7 +123,8 @@ def _worker_onehop(rank, world, port, n_local, K, seed, batch, out):
     if rank == 0:
         np.savez(out, p_gloo=res["gloo"][0], p_one=res["onehop"][0], m_gloo=res["gloo"][1], m_one=res["onehop"][1],
                  p_again=res["onehop_again"][0], p_fused=res["fused"][0], m_fused=res["fused"][1],
-                 odd_gloo=res["gloo_odd"], odd_fused=res["fused_odd"], odd_onehop=res["onehop_odd"])
+                 odd_gloo=res["gloo_odd"], odd_fused=res["fused_odd"], odd_onehop=res["onehop_odd"],
+                 two_gloo=res["gloo2"], two_fused=res["fused2"])
     dist.destroy_process_group()
 
 
@@ -126,6 +146,8 @@ def test_onehop_exchange_equals_the_collective(tmp_path, pocs, plan, env):
     # 21 waypoints, three calls in a row on the same buffers: every call of both one-hop forms equals the collective's
     assert list(got["odd_fused"]) == list(got["odd_gloo"]) and list(got["odd_onehop"]) == list(got["odd_gloo"])
     assert len(set(got["odd_gloo"])) == len(got["odd_gloo"])
+    # two engines in flight (bench.py POCS_ENGINES=2): the same bits as the collective, batch by batch
+    assert list(got["two_fused"]) == list(got["two_gloo"]) and len(got["two_gloo"]) == 2 * batch
     with pocs.Context(0) as c:                              # and both equal one process on the whole mixture
         c.configure(plan, env, K=K, N=2 * n_local, seed=seed)
         c.set_batch(batch)

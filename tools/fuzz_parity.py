@@ -2,8 +2,9 @@
 """Extended differential run of the HIP path against the CPU oracle: random worlds (rotated boxes,
 off-centre footprints, noise levels, landmark sets, sub-plans, K, N, seeds, batches), more and larger
 than tests/test_gpu_parity.py::test_randomised_configurations_match_oracle affords in the suite.
-Checks per case: per-waypoint probabilities and last-waypoint flags of the GMM path, hit counters of
-the MC path -- all exact.  usage: fuzz_parity.py [cases] [max_N] [seed]"""
+Checks per case, ALL exact (numerics v7: the oracle restates the summation tree): moments, mixture states and
+probabilities of every waypoint, the last waypoint's flags, of run 0 and of the last run of a random batch;
+hit counters of the MC path.  usage: fuzz_parity.py [cases] [max_N] [seed]"""
 import sys
 import time
 from pathlib import Path
@@ -41,11 +42,20 @@ with pocs_amd.Context(0) as ctx:
                       cov0=(np.eye(3) * rng.uniform(2e-4, 4e-3)).tolist())
         cfg = orc.config(pl, env, K=K, alphas=params["alphas"], Q=params["Q"], landmarks=lm, cov0=params["cov0"])
         ctx.configure(pl, env, params=params, K=K, N=N, seed=seed)
+        R = int(rng.choice([1, 1, 2, 5, 17]))
+        ctx.set_batch(R)
+        ctx.run_gmm_estimation()
+        finals = list(ctx.batch_probabilities())
+        ok = True
+        for r in sorted({0, R - 1}):
+            want = orc.run_gmm(cfg, (seed + r * 0x9E3779B97F4A7C15) % 2 ** 64, N, want_samples=True)
+            ctx.select_batch_run(r)
+            got_m = np.array([ctx.moments(w, K) for w in range(W)])
+            got_s = np.array([ctx.gmm_state_raw(w, K) for w in range(W)])[..., :14]
+            ok = ok and np.array_equal(got_m, want["moments"]) and np.array_equal(got_s, want["states"][..., :14]) \
+                and np.array_equal(ctx.waypoint_probabilities(), want["probs"]) and finals[r] == want["prob"] \
+                and np.array_equal(ctx.gmm_samples(N)[1], want["flags"])
         ctx.set_batch(1)
-        p = ctx.run_gmm_estimation()
-        want = orc.run_gmm(cfg, seed, N, want_samples=True)
-        ok = np.array_equal(ctx.waypoint_probabilities(), want["probs"]) and abs(p - want["prob"]) < 1e-12 \
-            and np.array_equal(ctx.gmm_samples(N)[1], want["flags"])
         ctx.set_seed(seed)
         p_mc = ctx.run_simulation()
         n_mc, hits, _ = orc.run_mc(cfg, seed, N)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Soak test of the in-launch hand-off (block partials -> ticket -> last block -> mixture advance):
-many runs at varied, uneven sizes, each repeated with the same seed -- every repeat must be
-bitwise identical (a stale or torn partial row would change the sums)."""
+"""Soak test of the in-launch hand-off (rows of the virtual slices -> ticket -> last block -> mixture advance):
+many runs at varied, uneven sizes and batches, each repeated with the same seed -- every repeat must be
+bitwise identical (a stale or torn row would change the sums) -- and, the sums being defined on a run's virtual
+slices and not on the launch, identical to the same runs issued one per call."""
 import sys
 import time
 from pathlib import Path
@@ -36,5 +37,10 @@ with pocs_amd.Context(0) as c:
                 print("MISMATCH K=%d N=%d R=%d seed=%d rep=%d" % (K, N, R, seed, rep))
             runs += R
         c.set_batch(1)
+        c.set_seed(seed)
+        c.run_gmm_estimation()                      # run 0 on its own launch: the same bits as run 0 of the batch
+        if (c.batch_probabilities()[0],) != ref[0][:1]:
+            bad += 1
+            print("MISMATCH batch vs single K=%d N=%d R=%d seed=%d" % (K, N, R, seed))
 print("soak: %d runs in %.0f s, %d mismatches" % (runs, time.time() - t0, bad))
 sys.exit(1 if bad else 0)
