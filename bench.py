@@ -524,6 +524,10 @@ def main():
                 "algorithmic_bytes_per_launch": bpe * units, "bytes_per_eval": bpe, "evals_per_launch": units,
                 "avg_kernel_us": avg_ms * 1e3, "concurrent_launches": groups, "waypoint_us": waypoint_us,
                 "evals_per_s_in_kernel": units / (avg_ms * 1e-3) if avg_ms > 0 else 0.0}
+    if args.mc_fused:
+        roofline["note"] = ("fused roll-out: the particle stays in registers for all waypoints, ~0 algorithmic bytes per evaluation "
+                            "(28 B per particle per RUN) -- an FP64-issue kernel whose roofline is not HBM; read evals_per_s_in_kernel, "
+                            "not frac (SURVEY 8d: reported separately from the streaming kernel)")
     if dist is not None:                               # every rank's kernel time, so that a scaling run explains itself
         t = torch.zeros(world, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         t[rank] = avg_ms * 1e3

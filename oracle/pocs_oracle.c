@@ -33,9 +33,11 @@
  *   - degenerate truncation cases (a component with < 2 survivors is retired).
  *
  * Pinning status: see oracle/README.md -- pinned against the reference's fixtures where they
- * exist (odometry.dat == inverseOdometry(trajectory.dat); Armadillo's fn_cov known answers;
- * the compiled Armadillo / GM_Model.h pieces in oracle/_ref); the EKF chain and the OpenRAVE
- * collision result are "parity unpinned" (MCSimulator.h needs <openrave/plugin.h>, absent here).
+ * exist (odometry.dat == inverseOdometry(trajectory.dat); Armadillo's fn_cov known answers), against the
+ * compiled Armadillo / GM_Model.h pieces and -- round 3 -- against the reference's own EKF member functions
+ * (MCSimulator.h:368-553,868-929 cut from the header and compiled: oracle/_ref).  "Parity unpinned": the
+ * OpenRAVE collision result (not in the reference tree) and the order of the driver loop EKF_GaussProp
+ * (its body names OpenRAVE members; MCSimulator.h as a whole needs <openrave/plugin.h>, absent here).
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; fma() is always explicit).
  */
@@ -775,12 +777,12 @@ static void tree_moments(int K, long long count, const double* pts, const unsign
   while ((2LL << sh) <= chunks && (2 << sh) <= 256) ++sh;
   int VS = 1 << sh;
   double* rows = (double*)calloc((size_t)VS * ORC_MAX_K * (NS + 1), sizeof(double));   /* [slice][k][n, 9 sums] */
-  static double chain[ORC_MAX_K][LANES][NS];
+  double (*chain)[LANES][NS] = malloc(sizeof(double[ORC_MAX_K][LANES][NS]));           /* (not static: bench.py times the oracle on many threads) */
   for (int j = 0; j < VS; ++j) {
     long long cb = ((long long)j * chunks) >> sh, ce = ((long long)(j + 1) * chunks) >> sh;
     for (int v = 0; v < WAVES; ++v) {
       long long n_k[ORC_MAX_K];
-      for (int k = 0; k < K; ++k) { n_k[k] = 0; memset(chain[k], 0, sizeof chain[k]); }
+      for (int k = 0; k < K; ++k) { n_k[k] = 0; memset(chain[k], 0, sizeof(double[LANES][NS])); }
       for (long long c = cb; c < ce; ++c)
         for (int l = 0; l < LANES; ++l) {
           long long lp = c * TB + (long long)v * LANES + l;
@@ -828,6 +830,7 @@ static void tree_moments(int K, long long count, const double* pts, const unsign
     }
   }
   free(rows);
+  free(chain);
 }
 
 int orc_gmm_waypoint(const orc_config* cfg, uint64_t seed, int waypoint, const double* state,

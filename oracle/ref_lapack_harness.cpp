@@ -6,7 +6,7 @@
 // image's scipy wheel (scipy.libs/libscipy_openblas-*.so: a library that is present, LP64, symbols
 // prefixed `scipy_`, mapped with -D<sym>_=scipy_<sym>_ by the Makefile).  Built by
 // `make -C oracle ref_lapack` only where /root/reference is mounted; output in oracle/_ref/
-// (git-ignored, gpurun-ignored: it never travels).  Test infrastructure only.
+// (git-ignored; the built library travels to the GPU box, no source does).  Test infrastructure only.
 //
 // Armadillo's generator cannot be shared with the build (it is mt19937_64 + std::normal_distribution,
 // arma_rng_cxx11.hpp:24-111), so every entry point also returns the TAPE of standard normals the

@@ -1,15 +1,14 @@
 #!/bin/bash
-# A/B sweep of bench.py on one GPU: one launch per waypoint (k_gmm_step, the default) against the
-# queue-driven kernel (POCS_PERSISTENT=1, k_gmm_run), at the driver's invocation (--steps 20 --warmup 5),
-# the default (256 / 64) and small batches.  usage: tools/bench_sweep.sh out.txt
+# Sweep of bench.py on one GPU: the driver's invocation (--steps 20 --warmup 5), the default (256 / 64) and small
+# batches, with one and with two sub-batches per call (POCS_GMM_GROUPS).  usage: tools/bench_sweep.sh out.txt
 out=${1:-gpurun_out/sweep.txt}; shift
 : > "$out"
 run() { echo "## $*" >> "$out"; env "$@" >> "$out" 2>> "$out.err" || echo "FAILED: $*" >> "$out"; }
-for pers in 0 1; do
-  run POCS_PERSISTENT=$pers python bench.py --steps 20 --warmup 5 --no-cpu-baseline
-  run POCS_PERSISTENT=$pers python bench.py --steps 256 --warmup 64 --no-cpu-baseline
-  run POCS_PERSISTENT=$pers python bench.py --batch 1 --steps 16 --warmup 4 --no-cpu-baseline
-  run POCS_PERSISTENT=$pers python bench.py --batch 8 --steps 32 --warmup 8 --no-cpu-baseline
+for g in 1 2; do
+  run POCS_GMM_GROUPS=$g python bench.py --steps 20 --warmup 5 --no-cpu-baseline
+  run POCS_GMM_GROUPS=$g python bench.py --steps 256 --warmup 64 --no-cpu-baseline
+  run POCS_GMM_GROUPS=$g python bench.py --batch 1 --steps 16 --warmup 4 --no-cpu-baseline
+  run POCS_GMM_GROUPS=$g python bench.py --batch 8 --steps 32 --warmup 8 --no-cpu-baseline
 done
 python - "$out" <<'PY'
 import json, sys
