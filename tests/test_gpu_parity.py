@@ -283,6 +283,41 @@ def test_graph_replays_survive_readbacks(pocs, plan, env, mc):
     assert sequence(1) == sequence(0)
 
 
+def test_sub_batches_on_side_streams_change_no_bit(tmp_path):
+    """POCS_GMM_GROUPS = 2, 3: a call's runs issued as sub-batches on side streams (graph forked and joined by
+    events; eager too), their launches overlapping: every run's probabilities and moments as with one launch per
+    waypoint for all of them."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    code = (
+        "import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+        "import pocs_amd\n"
+        "plan, env = pocs_amd.load_plan(), pocs_amd.load_env()\n"
+        "h = hashlib.sha256()\n"
+        "with pocs_amd.Context(0) as c:\n"
+        "    for graph in (1, 0):\n"
+        "        c.configure(plan, env, K=3, N=100001, seed=5)\n"
+        "        c.set_option(pocs_amd.OPT_USE_GRAPH, graph)\n"
+        "        c.set_batch(17)\n"
+        "        for rep in range(2):\n"
+        "            c.run_gmm_estimation()\n"
+        "            h.update(np.array(c.batch_probabilities()).tobytes())\n"
+        "            for r in (0, 8, 16):\n"
+        "                c.select_batch_run(r)\n"
+        "                h.update(np.array([c.moments(w, 3) for w in range(56)]).tobytes())\n"
+        "print(h.hexdigest())\n" % str(root))
+    digests = {}
+    for g in ("1", "2", "3"):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True,
+                             env=dict(os.environ, POCS_GMM_GROUPS=g))
+        digests[g] = out.stdout.strip().splitlines()[-1]
+    assert digests["1"] == digests["2"] == digests["3"], digests
+
+
 def test_batch_equals_consecutive_single_runs(ctx, plan, env):
     """R estimations advanced in lockstep (one launch per waypoint for all of them) must give,
     bit for bit, what R consecutive single runs give."""
@@ -586,6 +621,12 @@ def test_error_behaviour(pocs, plan, env):
             assert e.value.code == -3 and "collision world" in str(e.value)
         c.SendCommand("clearObstacles")                           # an explicitly empty world is a world
         assert float(c.SendCommand("runGMMEstimation")) == 0.0
+        # positions inside a shard are 32-bit in the kernels: a larger shard is refused before anything is allocated
+        c.SendCommand("setNumGMMSamples 3000000000")
+        with pytest.raises(pocs.PocsError) as e:
+            c.SendCommand("runGMMEstimation")
+        assert e.value.code == -1 and "shard" in str(e.value)
+        c.SendCommand("setNumGMMSamples 100")
         assert float(c.SendCommand("runSimulation")) == 0.0
         with pytest.raises(pocs.PocsError) as e:
             c.SendCommand("setNumGaussians 9")
