@@ -23,7 +23,7 @@
 #include "../../include/pocs.h"
 #include "pocs_kernels.h"
 
-#define POCS_VERSION_STRING "pocs-mi355x 0.1 (gfx950; numerics v6)"
+#define POCS_VERSION_STRING "pocs-mi355x 0.3 (gfx950; numerics v7)"
 
 namespace {
 

@@ -10,7 +10,7 @@
 // GMM kernels: TWO blocks of 512 threads per CU = four waves per SIMD at <= 128 VGPRs.  The sampling body
 // keeps one component's sums per thread whatever K is, so one shape serves every K (measured at K = 8,
 // 10^7 samples, 16 runs: 2 x 512 0.39 of the HBM peak, 1 x 768 and 3 x 256 0.40, 2 x 384 0.31).  Two
-// co-resident blocks instead of one fat one: while one block is in the head or tail of a task (parameter
+// co-resident blocks instead of one fat one: while one block is in its head or tail (parameter
 // staging, block reduction, the drain of its stores, ticket, mixture advance) the other block's waves
 // have the CU's issue slots.
 #ifdef POCS_GMM_BLOCK                      // sweeps: force one size for every K
@@ -106,7 +106,7 @@ struct pocs_gmm_launch {
   int advance_in_tail;           // 1: the last block also builds state/param[waypoint+1] (single GPU)
   int exchange_in_tail;          // 1: ... after exchanging the run's moments with the other ranks through `xchg` (sharded)
   pocs_xchg_dev xchg;
-  // task geometry (above)
+  // launch geometry (above)
   long long chunks;              // of the shard
   int vs_shift;                  // VS = 1 << vs_shift virtual slices per run
   int upb;                       // units per block (<= VS)

@@ -105,8 +105,8 @@ __device__ __forceinline__ void stage_env(const pocs_env_dev* __restrict__ env, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Hand-offs between workgroups inside a launch (partial rows -> last arriver; mixture state and
-// sampler parameters -> the tasks of the next waypoint).  cdna_hip_programming.md Guideline 16,
+// Hand-offs between workgroups (the rows of a run's virtual slices -> the last arriver, inside a launch; mixture
+// state and sampler parameters -> the blocks of the next waypoint's launch).  cdna_hip_programming.md Guideline 16,
 // form R1: every handed-off byte is stored write-through (`sc1`: a relaxed agent-scope atomic
 // store), every storing wave drains its stores (s_waitcnt vmcnt(0)), the block meets, ONE lane
 // signals with an agent-scope atomic (ticket add / `ready` store).  The consumer polls or draws
