@@ -13,3 +13,4 @@ print('$f: value %.4g ms/step %.4f single %s kernel %.1f us frac %.3f traffic_fr
 print('   limiter', {k: v for k, v in r['limiter'].items() if k != 'kind'})
 if 'cpu_baseline' in d: print('   cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('all_cores'))
 "; done
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
