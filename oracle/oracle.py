@@ -59,6 +59,19 @@ class Oracle:
         0: plain sequential sums over the free set in sample order."""
         self.lib.orc_set_sum_order(C.c_int(1 if order else 0))
 
+    def set_tapes(self, chain=None, init=None, gmm=None, counts=None):
+        """Test hook: standard normals from tapes instead of Philox (None = Philox).  chain: (W-1) x (3 + L), a
+        step's r1 tr r2 z_0..; init: N x 3 (MC particles); gmm: W x N x 3 (a waypoint's samples, the components'
+        blocks one after the other); counts: W x K samples per component, in place of the conditional binomials.
+        The arrays are kept alive here until the next call."""
+        keep = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (chain, init, gmm)]
+        cnt = None if counts is None else np.ascontiguousarray(counts, np.int64)
+        self._tapes = keep + [cnt]
+        stride = 0 if keep[0] is None else keep[0].shape[1]
+        n_gmm = 0 if keep[2] is None else keep[2].shape[1]
+        self.lib.orc_set_tapes(_p(keep[0]), C.c_int(stride), _p(keep[1]), _p(keep[2]), C.c_longlong(n_gmm),
+                               None if cnt is None else cnt.ctypes.data_as(C.POINTER(C.c_longlong)))
+
     # ---- primitives -------------------------------------------------------------------
     def philox(self, ctr, key, rounds=10):
         c = (C.c_uint32 * 4)(*ctr)

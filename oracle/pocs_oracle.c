@@ -35,9 +35,11 @@
  * Pinning status: see oracle/README.md -- pinned against the reference's fixtures where they
  * exist (odometry.dat == inverseOdometry(trajectory.dat); Armadillo's fn_cov known answers), against the
  * compiled Armadillo / GM_Model.h pieces and -- round 3 -- against the reference's own EKF member functions
- * (MCSimulator.h:368-553,868-929 cut from the header and compiled: oracle/_ref).  "Parity unpinned": the
- * OpenRAVE collision result (not in the reference tree) and the order of the driver loop EKF_GaussProp
- * (its body names OpenRAVE members; MCSimulator.h as a whole needs <openrave/plugin.h>, absent here).
+ * (MCSimulator.h:368-553,868-929 cut from the header and compiled: oracle/_ref) and its whole estimator loop
+ * (runSimulation / runGMMEstimation, :94-129,158-235,241-266,287-365,559-864 compiled the same way, run on seeded
+ * generators; this file then runs on the SAME normals through orc_set_tapes: tests/test_oracle_vs_ref_loop.py).
+ * "Parity unpinned": the OpenRAVE collision result (checkCollision(const config&), :269-285; not in the
+ * reference tree -- MCSimulator.h as a whole needs <openrave/plugin.h>, absent here).
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; fma() is always explicit).
  */
@@ -593,7 +595,31 @@ typedef struct {
   const double* boxes;  /* M x 5 */
 } orc_config;
 
+/* Test hook (tests/test_oracle_vs_ref_loop.py): standard normals from TAPES instead of Philox, so that a run can be
+ * repeated on the noise the reference's compiled loop (oracle/_ref/libpocs_ref_loop.so) drew from arma::randn and
+ * compared value for value.  chain: (W-1) x stride, a step's r1 tr r2 z_0..z_{L-1}; init: 3 per MC particle; gmm:
+ * per waypoint 3 per sample, n_gmm samples a waypoint; counts: per waypoint K component counts (the reference draws
+ * them from GM_Model's own engine and prints them), replacing the conditional binomials.  NULL = that stream stays
+ * on Philox.  Not thread-safe. */
+static const double *g_tape_chain = NULL, *g_tape_init = NULL, *g_tape_gmm = NULL;
+static const long long* g_tape_counts = NULL;
+static int g_tape_stride = 0;
+static long long g_tape_n_gmm = 0;
+void orc_set_tapes(const double* chain, int stride, const double* init, const double* gmm, long long n_gmm,
+                   const long long* counts) {
+  g_tape_chain = chain; g_tape_stride = stride; g_tape_init = init; g_tape_gmm = gmm; g_tape_n_gmm = n_gmm;
+  g_tape_counts = counts;
+}
+
+/* orc_collides on a configuration's footprint and boxes, in the shape of a callback (the compiled reference loop of
+ * oracle/ref_loop_harness.cpp takes its collision predicate this way). */
+int orc_collides_cfg(double x, double y, double th, const void* cfg_) {
+  const orc_config* cfg = (const orc_config*)cfg_;
+  return orc_collides(x, y, th, cfg->fp, cfg->boxes, cfg->M);
+}
+
 static double chain_normal(uint64_t seed, int step, int k) {
+  if (g_tape_chain) return g_tape_chain[(size_t)step * (size_t)g_tape_stride + (size_t)k];
   uint32_t w[4];
   double a, b;
   draw(seed, (uint64_t)step, 0, 1 /* chain stream */, (uint32_t)(k / 2), w);
@@ -689,6 +715,7 @@ long long orc_run_mc(const orc_config* cfg, uint64_t seed, long long first, long
     double zz[3];
     uint32_t spare;
     orc_normal3(seed, (uint64_t)(first + i), 0, 2 /* mc-init stream */, zz, &spare);
+    if (g_tape_init) memcpy(zz, g_tape_init + 3 * (size_t)(first + i), sizeof zz);
     double p[3];                                                         /* initParticles :287-297 */
     p[0] = fma(L0[0], zz[0], mu0[0]);
     p[1] = fma(L0[2], zz[1], fma(L0[1], zz[0], mu0[1]));
@@ -845,6 +872,10 @@ int orc_gmm_waypoint(const orc_config* cfg, uint64_t seed, int waypoint, const d
     if (st[13] != 0.0) orc_chol3_lower(st + 3, chol[k]);
   }
   orc_component_counts(K, state, seed, waypoint, n_total, table);
+  if (g_tape_counts) {
+    double run = 0.0;
+    for (int k = 0; k < K; ++k) { run += (double)g_tape_counts[(size_t)waypoint * (size_t)K + (size_t)k]; table[k] = run; }
+  }
   /* the reference keeps one matrix of points per component (GM_Model.h:99-107) and takes
    * mean / cov of the free columns afterwards (MCSimulator.h:592-598); do the same. */
   double* free_pts[ORC_MAX_K];
@@ -861,6 +892,7 @@ int orc_gmm_waypoint(const orc_config* cfg, uint64_t seed, int waypoint, const d
     uint32_t spare;
     orc_sample_normals(seed, (uint64_t)(first + i), (uint32_t)waypoint, 3 /* gmm stream */, zz, &spare);
     (void)spare;
+    if (g_tape_gmm) memcpy(zz, g_tape_gmm + 3 * ((size_t)waypoint * (size_t)g_tape_n_gmm + (size_t)(first + i)), sizeof zz);
     double gidx = (double)(first + i);                /* component = first one whose running count exceeds the index */
     int k = 0;
     for (int j = 0; j < K - 1; ++j) if (table[j] <= gidx) ++k;

@@ -146,7 +146,7 @@ __device__ __forceinline__ void acquire_agent() {
 }
 
 #if defined(POCS_STAMPS)       // diagnostic build (tools/stamps.sh): where the blocks of a k_gmm_step launch spend their time
-__device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_stamps[24];
 #define POCS_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_stamps[i], n_ - last_); last_ = n_; } } while (0)
 #else
 #define POCS_STAMP(i) do { } while (0)
@@ -277,6 +277,35 @@ __device__ __forceinline__ void advance_stage(const pocs_gmm_launch& a, int K, i
 // one wave, after advance_stage (+ barrier): one component per lane
 __device__ __forceinline__ void advance_components(const pocs_gmm_launch& a, int K, int w, int r, int lane, double* scratch) {
   const adv_ptrs p = advance_ptrs(a, K, w, r, scratch);
+#if defined(POCS_STAMPS)
+  if (lane < K && w > 0) {
+    // the pieces of pocs_gmm_advance_component with the cycle counter read between them (alive components only)
+    const int k = lane;
+    const double* pv = p.l_prev + k * POCS_STATE_STRIDE;
+    const pocs_sensor* sen = reinterpret_cast<const pocs_sensor*>(p.l_sen);
+    unsigned long long c0 = __builtin_readcyclecounter(), c1;
+    double tm[3], tc[9], pm[3], pc[9], L[6];
+    double mom[POCS_NMOM];
+    for (int i = 0; i < POCS_NMOM; ++i) mom[i] = p.l_mom[k * POCS_NMOM + i];
+    double keepalive = pv[13];
+    asm volatile("" : "+v"(keepalive));
+#define CYC(i) do { c1 = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_stamps[i], c1 - c0); c0 = c1; } while (0)
+    CYC(16);
+    int ok = pocs_truncated_moments(mom, tm, tc);
+    asm volatile("" : "+v"(tc[8]), "+v"(tm[2]));
+    CYC(17);
+    pocs_ekf_predict(tm, tc, p.l_ch, p.l_ch + 3, pm, pc);
+    asm volatile("" : "+v"(pc[8]), "+v"(pm[2]));
+    CYC(18);
+    pocs_ekf_update(pm, pc, p.l_ch + POCS_CHAIN_Z, sen);
+    asm volatile("" : "+v"(pc[8]), "+v"(pm[2]));
+    CYC(19);
+    ok &= pocs_chol3_lower(pc, L);
+    asm volatile("" : "+v"(L[5]));
+    CYC(20);
+    (void)ok;
+  }
+#endif
   if (lane < K)
     pocs_gmm_advance_component(lane, p.l_prev, (w == 0) ? nullptr : p.l_mom, p.l_ch, p.l_ch + 3, p.l_ch + POCS_CHAIN_Z,
                                reinterpret_cast<const pocs_sensor*>(p.l_sen), p.l_next, p.l_par);
@@ -324,12 +353,22 @@ __device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, 
 // The whole advance to waypoint w by a block of >= 128 threads (every thread calls it).
 __device__ __forceinline__ void advance_block(const pocs_gmm_launch& a, int K, int w, int r, double* adv, double* spec,
                                               bool mom_in_lds, int tid, int nthreads) {
+#if defined(POCS_STAMPS)
+  unsigned long long t_ = wall_clock64();
+#define POCS_ADV_STAMP(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_stamps[i], n_ - t_); t_ = n_; } } while (0)
+#else
+#define POCS_ADV_STAMP(i) do { } while (0)
+#endif
   advance_stage(a, K, w, r, adv, mom_in_lds, tid, nthreads);
   __syncthreads();
+  POCS_ADV_STAMP(8);
   if (tid < 64) advance_components(a, K, w, r, tid, adv);
   else if (tid == 64 && w > 0) speculate_counts(a, K, w, r, adv, spec);
+  POCS_ADV_STAMP(9);
   __syncthreads();
+  POCS_ADV_STAMP(10);
   if (tid < 64) advance_finish(a, K, w, r, tid, adv, w > 0 ? spec : nullptr);
+  POCS_ADV_STAMP(11);
 }
 __global__ __launch_bounds__(128) void k_gmm_advance(pocs_gmm_launch a, int K) {
   __shared__ double s_adv[POCS_ADV_SCRATCH(POCS_MAX_GAUSSIANS)];
@@ -1104,13 +1143,16 @@ hipError_t launch_gmm_k(const pocs_gmm_launch& a, hipStream_t s) {
 
 #if defined(POCS_STAMPS)
 extern "C" void pocs_stamps_report() {
-  unsigned long long h[16];
+  unsigned long long h[24];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) != hipSuccess || h[15] == 0) return;
   const double nb = (double)h[15], nc = (double)(h[14] ? h[14] : 1);
   fprintf(stderr, "[stamps] %.0f blocks, %.0f closers; per block (us): head %.2f | units %.2f | -> barrier %.2f | rows + drain + barrier %.2f | "
-          "ticket + barrier %.2f ; per closer: close_sums %.2f | advance %.2f\n", nb, nc, 0.01 * h[0] / nb, 0.01 * h[1] / nb, 0.01 * h[2] / nb,
-          0.01 * h[3] / nb, 0.01 * h[4] / nb, 0.01 * h[5] / nc, 0.01 * h[6] / nc);
-  unsigned long long z[16] = {0};
+          "ticket + barrier %.2f ; per closer: close_sums %.2f | advance %.2f (staging %.2f, components (wave 0) %.2f, -> the counts lane %.2f, normalise + publish + drain %.2f)\n",
+          nb, nc, 0.01 * h[0] / nb, 0.01 * h[1] / nb, 0.01 * h[2] / nb, 0.01 * h[3] / nb, 0.01 * h[4] / nb, 0.01 * h[5] / nc, 0.01 * h[6] / nc,
+          0.01 * h[8] / nc, 0.01 * h[9] / nc, 0.01 * h[10] / nc, 0.01 * h[11] / nc);
+  fprintf(stderr, "[stamps] a component done a second time, in pieces (cycles per closer): LDS reads %.0f | truncated moments %.0f | predict %.0f | update %.0f | chol %.0f\n",
+          (double)h[16] / nc, (double)h[17] / nc, (double)h[18] / nc, (double)h[19] / nc, (double)h[20] / nc);
+  unsigned long long z[24] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
 }
 #endif

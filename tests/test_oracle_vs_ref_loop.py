@@ -1,0 +1,201 @@
+"""The oracle's whole runs against the REFERENCE's own loop: `make -C oracle ref_loop` compiles MCSimulator.h's
+estimator loop -- `EKF_GaussProp`, `truncateGMM`, the particle functions, the setters, the data members, the EKF
+arithmetic -- from the header where it lies (oracle/ref_loop_harness.cpp lists the line ranges), against the
+vendored Armadillo and GM_Model.h.  The one member that touches OpenRAVE, `checkCollision(const config&)`
+(:269-285), is not taken; in its place the loop calls the oracle's 2-D predicate on this build's world (DESIGN.md 8,
+row C1: the scene itself cannot be pinned).  So what is pinned here is everything AROUND the collision check: the
+order of the loop (D1), which control feeds what, particles and their counters (P1-P3), the truncation and the
+mixture bookkeeping (T1), the final product (F1) -- on the reference's own noise: the harness replays the
+arma::randn calls of a run after the same seed and hands them over as tapes, and the oracle is run on those.
+Skips where oracle/_ref is absent."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+LIB = Path(__file__).resolve().parents[1] / "oracle" / "_ref" / "libpocs_ref_loop.so"
+pytestmark = pytest.mark.skipif(not LIB.exists(), reason="oracle/_ref/libpocs_ref_loop.so not built (no /root/reference)")
+
+TWO_PI = 2 * 3.14159265358979323846
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Ref:
+    """The compiled loop, configured like `orc.config(plan, env, K)`."""
+
+    def __init__(self, orc, pocs, plan, env):
+        self.lib = C.CDLL(str(LIB))
+        self.lib.refl2_run_mc.restype = C.c_double
+        self.lib.refl2_run_gmm.restype = C.c_double
+        self.lib.refl2_last_text.restype = C.c_longlong
+        self.orc, self.pocs, self.plan, self.env = orc, pocs, plan, env
+
+    def configure(self, particles, gaussians, samples):
+        d = self.pocs.DEFAULTS
+        lm = np.asarray(d["landmarks"], np.float64)
+        self.cfg = self.orc.config(self.plan, self.env, K=gaussians)
+        traj = np.ascontiguousarray(np.asarray(self.plan["traj"], np.float64).T)
+        odom = np.ascontiguousarray(np.asarray(self.plan["odom"], np.float64).T)
+        self.W, self.L, self.N, self.K = traj.shape[1], lm.shape[1], particles, gaussians
+        self.samples = samples
+        fn = C.cast(self.orc.lib.orc_collides_cfg, C.c_void_p)
+        self.lib.refl2_configure(_p(np.asarray(d["alphas"], np.float64)), C.c_double(d["Q"]), _p(np.ascontiguousarray(lm[0])),
+                                 _p(np.ascontiguousarray(lm[1])), C.c_int(self.L), _p(traj), _p(odom), C.c_int(self.W),
+                                 _p(np.ascontiguousarray(np.asarray(d["cov0"], np.float64))), C.c_int(particles),
+                                 C.c_int(gaussians), C.c_int(samples), fn, C.byref(self.cfg))
+        return self.cfg
+
+    def run_mc(self, seed):
+        mu, cov, parts = np.zeros(3), np.zeros(9), np.zeros((self.N, 3))
+        hits, checked = np.zeros(self.N, np.uint32), C.c_longlong(0)
+        p = self.lib.refl2_run_mc(C.c_uint(seed), _p(mu), _p(cov), _p(parts), hits.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(checked))
+        init, chain = np.zeros((self.N, 3)), np.zeros((self.W - 1, 3 + self.L))
+        self.lib.refl2_record_mc(C.c_uint(seed), C.c_int(self.N), C.c_int(self.W), C.c_int(self.L), _p(init), _p(chain))
+        return dict(p=p, mu=mu, cov=cov, particles=parts, hits=hits, checked=checked.value, init=init, chain=chain)
+
+    def run_gmm(self, seed, gen_seed=7, record=False):
+        mu, cov = np.zeros(3), np.zeros(9)
+        means, covs, checked = np.zeros((self.K, 3)), np.zeros((self.K, 9)), C.c_longlong(0)
+        p = self.lib.refl2_run_gmm(C.c_uint(seed), C.c_uint(gen_seed), _p(mu), _p(cov), _p(means), _p(covs), C.byref(checked))
+        text = self.last_text()
+        out = dict(p=p, mu=mu, cov=cov, means=means, covs=covs, checked=checked.value, probs=self.printed_probabilities(text),
+                   counts=self.printed_counts(text))
+        if record:
+            gmm, chain = np.zeros((self.W, self.samples, 3)), np.zeros((self.W - 1, 3 + self.L))
+            cnt = np.ascontiguousarray(out["counts"], np.int64)
+            self.lib.refl2_record_gmm(C.c_uint(seed), C.c_int(self.samples), C.c_int(self.W), C.c_int(self.L), C.c_int(self.K),
+                                      cnt.ctypes.data_as(C.POINTER(C.c_longlong)), _p(gmm), _p(chain))
+            out.update(gmm=gmm, chain=chain)
+        return out
+
+    def last_text(self):
+        n = self.lib.refl2_last_text(None, C.c_longlong(0))
+        buf = C.create_string_buffer(n + 1)
+        self.lib.refl2_last_text(buf, C.c_longlong(n + 1))
+        return buf.value.decode("ascii", "replace")
+
+    def printed_counts(self, text):
+        """The samples per component of every waypoint, as sampleNPoints prints them ("Counts Vector", GM_Model.h:95-96)."""
+        rows = [[int(t) for t in m.split()] for m in re.findall(r"Counts Vector\n([0-9 ]+)\n", text)]
+        assert len(rows) == self.W and all(len(r) == self.K and sum(r) == self.samples for r in rows), rows[:3]
+        return np.array(rows, np.int64)
+
+    def printed_probabilities(self, text):
+        """The row the loop prints after "Collision Probabilities:" (MCSimulator.h:845-846; Armadillo's four decimals)."""
+        m = re.search(r"Collision Probabilities:\n(.*?)\nCollision Free Probabilities:", text, re.S)
+        assert m, text[-2000:]
+        return np.array([float(t) for t in m.group(1).split()])
+
+
+@pytest.fixture(scope="module")
+def ref(orc, pocs, plan, env):
+    return Ref(orc, pocs, plan, env)
+
+
+@pytest.fixture(autouse=True)
+def philox_again(orc):
+    yield
+    orc.set_tapes()
+
+
+def angle_gap(a, b):
+    d = np.abs(np.asarray(a) - np.asarray(b)) % TWO_PI
+    return np.minimum(d, TWO_PI - d)
+
+
+def test_mc_run_on_the_reference_tape(ref, orc):
+    """runSimulation() with 300 particles, three seeds: the oracle on the same normals ends with the same belief
+    (1e-10), the same particles (1e-9; headings modulo 2 pi), the same collision counter for every particle and the
+    same proportion; and the reference checked N x W poses, as the oracle does."""
+    cfg = ref.configure(particles=300, gaussians=1, samples=10)
+    for seed in (11, 12, 13):
+        r = ref.run_mc(seed)
+        assert r["checked"] == 300 * ref.W
+        orc.set_tapes(chain=r["chain"], init=r["init"])
+        ch = orc.host_chain(cfg, 0)
+        n, hits, parts = orc.run_mc(cfg, 0, 300, want_particles=True)
+        assert np.allclose(ch["mu"][-1], r["mu"], rtol=0, atol=1e-10), (seed, ch["mu"][-1], r["mu"])
+        assert np.allclose(ch["cov"][-1], r["cov"], rtol=0, atol=1e-10), seed
+        assert np.allclose(parts[:, :2], r["particles"][:, :2], rtol=0, atol=1e-9), seed
+        assert np.all(angle_gap(parts[:, 2], r["particles"][:, 2]) < 1e-9), seed
+        assert np.array_equal(hits, r["hits"]), (seed, np.flatnonzero(hits != r["hits"]))
+        assert n / 300 == r["p"]
+        assert 0 < n < 300                                   # a run that separates colliding from free particles
+
+
+def test_gmm_run_with_one_gaussian_on_the_reference_tape(ref, orc):
+    """runGMMEstimation() with one Gaussian and 4000 samples (with one component every draw of the run is an
+    arma::randn call of known shape, so the whole run can be replayed): belief, the truncated-and-propagated Gaussian
+    after the last waypoint, every waypoint's probability as printed, and the final probability.  Sums are taken in
+    different orders (Armadillo's mean / cov against the build's tree): 1e-9."""
+    N = 4000
+    cfg = ref.configure(particles=10, gaussians=1, samples=N)
+    for seed in (21, 22):
+        r = ref.run_gmm(seed, record=True)
+        assert r["checked"] == N * ref.W
+        orc.set_tapes(chain=r["chain"], gmm=r["gmm"], counts=r["counts"])
+        ch = orc.host_chain(cfg, 0)
+        o = orc.run_gmm(cfg, 0, N)
+        assert np.allclose(ch["mu"][-1], r["mu"], rtol=0, atol=1e-10) and np.allclose(ch["cov"][-1], r["cov"], rtol=0, atol=1e-10)
+        assert np.allclose(o["probs"], r["probs"], rtol=0, atol=5.1e-5), (seed, o["probs"], r["probs"])     # four printed decimals
+        assert abs(o["prob"] - r["p"]) < 1e-12, (seed, o["prob"], r["p"])
+        # the mixture after the last waypoint's truncation: the reference stores mean / cov of the free samples there
+        # (:601-602); the oracle's last moments give the same through pocs_truncated_moments' formula
+        m = o["moments"][-1][0]
+        n = m[0]
+        mean = m[2:5] / n
+        assert np.allclose(mean, r["means"][0], rtol=0, atol=1e-9), (seed, mean, r["means"][0])
+        cxx = (m[5] - m[2] * m[2] / n) / (n - 1)
+        ctt = (m[10] - m[4] * m[4] / n) / (n - 1)
+        assert abs(cxx - r["covs"][0][0]) < 1e-9 and abs(ctt - r["covs"][0][8]) < 1e-9
+        assert 0.0 < r["p"] < 1.0
+
+
+def test_gmm_run_with_three_gaussians_on_the_reference_tape(ref, orc):
+    """Three Gaussians.  Which component a sample belongs to comes from GM_Model's own engine, but the run prints
+    every waypoint's counts (GM_Model.h:95-96): with those the arma::randn calls of the run have known shapes and the
+    whole run is replayed -- the oracle given the same counts and the same normals.  This is the mixture bookkeeping
+    end to end against the reference's loop: per-component truncation, the weights from the survivor counts, the
+    per-component EKF, the samples of a component as one block.  Per-waypoint probabilities as printed (four
+    decimals), the final probability, the three Gaussians after the last truncation."""
+    N = 3000
+    cfg = ref.configure(particles=10, gaussians=3, samples=N)
+    for seed, gen_seed in ((31, 5), (32, 6), (33, 7)):
+        r = ref.run_gmm(seed, gen_seed=gen_seed, record=True)
+        assert r["checked"] == N * ref.W and r["counts"].shape == (ref.W, 3)
+        assert r["counts"][0].min() > N / 4 and r["counts"][-1].min() >= 0             # equal weights at the start
+        orc.set_tapes(chain=r["chain"], gmm=r["gmm"], counts=r["counts"])
+        o = orc.run_gmm(cfg, 0, N)
+        assert np.allclose(o["probs"], r["probs"], rtol=0, atol=5.1e-5), (seed, o["probs"], r["probs"])
+        assert abs(o["prob"] - r["p"]) < 1e-12, (seed, o["prob"], r["p"])
+        for k in range(3):
+            m = o["moments"][-1][k]
+            if m[0] >= 2:
+                assert np.allclose(m[2:5] / m[0], r["means"][k], rtol=0, atol=1e-9), (seed, k)
+                assert abs((m[8] - m[3] * m[3] / m[0]) / (m[0] - 1) - r["covs"][k][4]) < 1e-9, (seed, k)
+        # the weights the oracle carries into each waypoint reproduce the counts' expectation: survivors / all survivors
+        w_last = o["states"][-1][:, 12]
+        free_prev = o["moments"][-2][:, 0]
+        assert np.allclose(w_last, free_prev / free_prev.sum(), rtol=0, atol=1e-15)
+
+
+def test_gmm_runs_with_three_gaussians_agree_in_law(ref, orc):
+    """The oracle's OWN component counts (conditional binomials on Philox) against the reference's (N categorical
+    draws on its engine), and everything downstream of them: 48 runs each way (2000 samples) on the same plan and
+    world.  The final probability of a run depends mostly on the path the chain realises, so the two sets of runs
+    are compared as samples of one distribution: means within four standard errors, and a two-sample
+    Kolmogorov-Smirnov test."""
+    from scipy import stats
+    N, runs = 2000, 48
+    cfg = ref.configure(particles=10, gaussians=3, samples=N)
+    a = np.array([ref.run_gmm(100 + s, gen_seed=500 + s)["p"] for s in range(runs)])
+    orc.set_tapes()
+    b = np.array([orc.run_gmm(cfg, 9000 + s, N)["prob"] for s in range(runs)])
+    se = np.sqrt(a.var(ddof=1) / runs + b.var(ddof=1) / runs)
+    assert abs(a.mean() - b.mean()) < 4 * se, (a.mean(), b.mean(), se)
+    assert stats.ks_2samp(a, b).pvalue > 1e-3, (np.sort(a), np.sort(b))
