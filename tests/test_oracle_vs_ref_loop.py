@@ -25,76 +25,10 @@ def _p(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-class Ref:
-    """The compiled loop, configured like `orc.config(plan, env, K)`."""
-
-    def __init__(self, orc, pocs, plan, env):
-        self.lib = C.CDLL(str(LIB))
-        self.lib.refl2_run_mc.restype = C.c_double
-        self.lib.refl2_run_gmm.restype = C.c_double
-        self.lib.refl2_last_text.restype = C.c_longlong
-        self.orc, self.pocs, self.plan, self.env = orc, pocs, plan, env
-
-    def configure(self, particles, gaussians, samples):
-        d = self.pocs.DEFAULTS
-        lm = np.asarray(d["landmarks"], np.float64)
-        self.cfg = self.orc.config(self.plan, self.env, K=gaussians)
-        traj = np.ascontiguousarray(np.asarray(self.plan["traj"], np.float64).T)
-        odom = np.ascontiguousarray(np.asarray(self.plan["odom"], np.float64).T)
-        self.W, self.L, self.N, self.K = traj.shape[1], lm.shape[1], particles, gaussians
-        self.samples = samples
-        fn = C.cast(self.orc.lib.orc_collides_cfg, C.c_void_p)
-        self.lib.refl2_configure(_p(np.asarray(d["alphas"], np.float64)), C.c_double(d["Q"]), _p(np.ascontiguousarray(lm[0])),
-                                 _p(np.ascontiguousarray(lm[1])), C.c_int(self.L), _p(traj), _p(odom), C.c_int(self.W),
-                                 _p(np.ascontiguousarray(np.asarray(d["cov0"], np.float64))), C.c_int(particles),
-                                 C.c_int(gaussians), C.c_int(samples), fn, C.byref(self.cfg))
-        return self.cfg
-
-    def run_mc(self, seed):
-        mu, cov, parts = np.zeros(3), np.zeros(9), np.zeros((self.N, 3))
-        hits, checked = np.zeros(self.N, np.uint32), C.c_longlong(0)
-        p = self.lib.refl2_run_mc(C.c_uint(seed), _p(mu), _p(cov), _p(parts), hits.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(checked))
-        init, chain = np.zeros((self.N, 3)), np.zeros((self.W - 1, 3 + self.L))
-        self.lib.refl2_record_mc(C.c_uint(seed), C.c_int(self.N), C.c_int(self.W), C.c_int(self.L), _p(init), _p(chain))
-        return dict(p=p, mu=mu, cov=cov, particles=parts, hits=hits, checked=checked.value, init=init, chain=chain)
-
-    def run_gmm(self, seed, gen_seed=7, record=False):
-        mu, cov = np.zeros(3), np.zeros(9)
-        means, covs, checked = np.zeros((self.K, 3)), np.zeros((self.K, 9)), C.c_longlong(0)
-        p = self.lib.refl2_run_gmm(C.c_uint(seed), C.c_uint(gen_seed), _p(mu), _p(cov), _p(means), _p(covs), C.byref(checked))
-        text = self.last_text()
-        out = dict(p=p, mu=mu, cov=cov, means=means, covs=covs, checked=checked.value, probs=self.printed_probabilities(text),
-                   counts=self.printed_counts(text))
-        if record:
-            gmm, chain = np.zeros((self.W, self.samples, 3)), np.zeros((self.W - 1, 3 + self.L))
-            cnt = np.ascontiguousarray(out["counts"], np.int64)
-            self.lib.refl2_record_gmm(C.c_uint(seed), C.c_int(self.samples), C.c_int(self.W), C.c_int(self.L), C.c_int(self.K),
-                                      cnt.ctypes.data_as(C.POINTER(C.c_longlong)), _p(gmm), _p(chain))
-            out.update(gmm=gmm, chain=chain)
-        return out
-
-    def last_text(self):
-        n = self.lib.refl2_last_text(None, C.c_longlong(0))
-        buf = C.create_string_buffer(n + 1)
-        self.lib.refl2_last_text(buf, C.c_longlong(n + 1))
-        return buf.value.decode("ascii", "replace")
-
-    def printed_counts(self, text):
-        """The samples per component of every waypoint, as sampleNPoints prints them ("Counts Vector", GM_Model.h:95-96)."""
-        rows = [[int(t) for t in m.split()] for m in re.findall(r"Counts Vector\n([0-9 ]+)\n", text)]
-        assert len(rows) == self.W and all(len(r) == self.K and sum(r) == self.samples for r in rows), rows[:3]
-        return np.array(rows, np.int64)
-
-    def printed_probabilities(self, text):
-        """The row the loop prints after "Collision Probabilities:" (MCSimulator.h:845-846; Armadillo's four decimals)."""
-        m = re.search(r"Collision Probabilities:\n(.*?)\nCollision Free Probabilities:", text, re.S)
-        assert m, text[-2000:]
-        return np.array([float(t) for t in m.group(1).split()])
-
-
 @pytest.fixture(scope="module")
 def ref(orc, pocs, plan, env):
-    return Ref(orc, pocs, plan, env)
+    import oracle
+    return oracle.RefLoop(orc, pocs, plan, env)
 
 
 @pytest.fixture(autouse=True)
