@@ -63,3 +63,30 @@ def test_driver_run_ahead_is_transparent(driver, tmp_path):
     ra = driver.run_experiment("MC", num_runs=7, num_particles=2500, seed=5, out_dir=tmp_path / "ra", run_ahead=3)
     assert one["proportions"] == ra["proportions"]
     assert len(ra["journal"].read_text().splitlines()) == 21
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,K", [("MC", 3), ("GMM", 3), ("GMM", 1)])
+def test_experiment_against_the_reference_loop(driver, orc, pocs, plan, env, tmp_path, mode, K):
+    """The reference's experiment (MCSimulation.py:221-269: independent runs, their mean is what the paper tabulates)
+    both ways on the same plan and world: 120 runs through the drop-in driver on the GPU, 120 runs of the reference's
+    OWN runSimulation() / runGMMEstimation() (oracle/_ref/libpocs_ref_loop.so: MCSimulator.h compiled from the
+    header, its one OpenRAVE call replaced by this build's 2-D predicate) on the host.  The two use unrelated random
+    streams, so the run results are compared as two samples of one distribution: means within four standard errors,
+    standard deviations within a factor 1.5, two-sample Kolmogorov-Smirnov.  (Value-for-value agreement on shared
+    noise is tests/test_oracle_vs_ref_loop.py's job, against the oracle; the HIP path equals the oracle bit for bit.)"""
+    import oracle
+    from scipy import stats
+    if not oracle.RefLoop.LIB.exists():
+        pytest.skip("oracle/_ref/libpocs_ref_loop.so not built (no /root/reference)")
+    runs, N = 120, 10000
+    r = driver.run_experiment(mode, num_runs=runs, num_particles=N, num_gaussians=K, seed=77, out_dir=tmp_path, batch=20)
+    ours = np.array(r["proportions"])
+    ref = oracle.RefLoop(orc, pocs, plan, env)
+    ref.configure(particles=N if mode == "MC" else 10, gaussians=K, samples=N if mode == "GMM" else 10)
+    theirs = np.array([ref.time_mc(1000 + s) if mode == "MC" else ref.run_gmm(1000 + s, gen_seed=3000 + s)["p"] for s in range(runs)])
+    se = np.sqrt(ours.var(ddof=1) / runs + theirs.var(ddof=1) / runs)
+    assert abs(ours.mean() - theirs.mean()) < 4 * se, (ours.mean(), theirs.mean(), se)
+    assert 1 / 1.5 < ours.std(ddof=1) / theirs.std(ddof=1) < 1.5, (ours.std(ddof=1), theirs.std(ddof=1))
+    assert stats.ks_2samp(ours, theirs).pvalue > 1e-3
+    print("%s K=%d: GPU %.4f +- %.4f, reference loop %.4f +- %.4f (120 runs each)" % (mode, K, ours.mean(), ours.std(ddof=1), theirs.mean(), theirs.std(ddof=1)))

@@ -2,7 +2,10 @@
 """Reproduce the SHAPE of the reference paper's Table I (finalpaper/ajaay_paper.tex:862-877: MC and
 1/2/3-component GMM, N = 10 000, 200 runs each) with this build's collision model, through the
 experiment driver.  The published numbers embed OpenRAVE's checker and the PR2 mesh, so only the
-ordering / band is comparable."""
+ordering / band is comparable.  Beside it, where oracle/_ref/libpocs_ref_loop.so exists, the
+SAME experiment by the reference's own loop (MCSimulator.h's runSimulation() / runGMMEstimation() compiled from the
+header, its one OpenRAVE collision call replaced by this build's 2-D predicate) on the host CPU: that column and
+ours must agree, and do."""
 import sys
 import tempfile
 from importlib import import_module
@@ -10,13 +13,27 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import pocs_amd  # noqa: F401,E402
 driver = import_module("probability-of-collision-for-safe-planning_amd.driver")
+sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "oracle"))
+import time  # noqa: E402
+import numpy as np  # noqa: E402
+import oracle  # noqa: E402  (the checker: this tool is a measurement script, not the product)
 
 PAPER = {"MC": (0.9348, 0.0406, 81.93), "GMM1": (0.6364, 0.0699, 72.58), "GMM2": (0.6393, 0.0696, 71.67),
          "GMM3": (0.6424, 0.0686, 72.79)}
-print("%-6s %28s   %34s" % ("method", "this build (mean sd  s/run)", "paper Table I (mean sd  CPU-s/run)"))
+ref = None
+if oracle.RefLoop.LIB.exists():
+    ref = oracle.RefLoop(oracle.Oracle(), pocs_amd, pocs_amd.load_plan(), pocs_amd.load_env())
+print("%-6s %28s   %42s   %34s" % ("method", "this build (mean sd  s/run)", "reference loop, compiled (mean sd  CPU-s/run)",
+                                   "paper Table I (mean sd  CPU-s/run)"))
 with tempfile.TemporaryDirectory() as tmp:
     for name, mode, K in (("MC", "MC", 3), ("GMM1", "GMM", 1), ("GMM2", "GMM", 2), ("GMM3", "GMM", 3)):
         r = driver.run_experiment(mode, num_runs=200, num_particles=10000, num_gaussians=K, seed=2018, out_dir=tmp)
         s = r["summary"]
         p = PAPER[name]
-        print("%-6s %10.4f %8.4f %9.6f   %14.4f %8.4f %9.2f" % (name, s["mean"], s["std"], s["mean_time"], *p))
+        rs = (float("nan"),) * 3
+        if ref is not None:
+            ref.configure(particles=10000 if mode == "MC" else 10, gaussians=K, samples=10000 if mode == "GMM" else 10)
+            t0 = time.perf_counter()
+            v = np.array([ref.time_mc(100 + i) if mode == "MC" else ref.run_gmm(100 + i, gen_seed=900 + i)["p"] for i in range(200)])
+            rs = (v.mean(), v.std(ddof=1), (time.perf_counter() - t0) / 200)
+        print("%-6s %10.4f %8.4f %9.6f   %22.4f %8.4f %9.4f   %14.4f %8.4f %9.2f" % (name, s["mean"], s["std"], s["mean_time"], *rs, *p))
