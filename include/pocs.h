@@ -84,6 +84,10 @@ int pocs_send_command(pocs_ctx* ctx, const char* line, char* out, size_t cap);
 #define POCS_OPT_PERSISTENT 6      /* retired (round 3): 0 is accepted, 1 returns POCS_E_ARG.  Round 2's queue-driven whole-call kernel
                                       (k_gmm_run) was slower than one launch per waypoint at every batch size measured and is gone
                                       (DESIGN.md section 5). */
+#define POCS_OPT_LONE_CALL 7       /* 1 (default): a whole-run GMM call of ONE run (batch 1, no run-ahead, one GPU) uses launches that close
+                                      the previous waypoint in every block's head instead of tickets and a closing block (no one else
+                                      is in flight to hide a closer behind): 10 % less time per waypoint, the same bits
+                                      (tests/test_gpu_parity.py::test_lone_call_changes_no_bit).  0: the ticket form always. */
 int pocs_set_option(pocs_ctx* ctx, int option, long long value);
 
 /* ---- batches of independent runs (ours) --------------------------------------------------

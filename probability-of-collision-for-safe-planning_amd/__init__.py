@@ -6,7 +6,7 @@ The directory name is not a Python identifier; import it through the alias modul
 at the repo root (or importlib.import_module with the literal name).
 """
 from . import planio  # noqa: F401
-from .capi import (Context, PocsError, load_library, library_path, OPT_MC_FUSED, OPT_PERSISTENT, OPT_PROFILE, OPT_RUN_AHEAD,  # noqa: F401
+from .capi import (Context, PocsError, load_library, library_path, OPT_LONE_CALL, OPT_MC_FUSED, OPT_PERSISTENT, OPT_PROFILE, OPT_RUN_AHEAD,  # noqa: F401
                    OPT_STORE_SAMPLES, OPT_USE_GRAPH, SIGNATURES)
 from .planio import DEFAULTS, load_env, load_plan, resample_plan  # noqa: F401
 

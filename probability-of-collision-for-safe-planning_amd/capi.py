@@ -13,7 +13,7 @@ from . import build as _build
 
 POCS_OK = 0
 E_ARG, E_ORDER, E_STATE, E_DEVICE, E_UNKNOWN_COMMAND, E_BUFFER = -1, -2, -3, -4, -5, -6
-OPT_STORE_SAMPLES, OPT_MC_FUSED, OPT_USE_GRAPH, OPT_PROFILE, OPT_RUN_AHEAD, OPT_PERSISTENT = 1, 2, 3, 4, 5, 6
+OPT_STORE_SAMPLES, OPT_MC_FUSED, OPT_USE_GRAPH, OPT_PROFILE, OPT_RUN_AHEAD, OPT_PERSISTENT, OPT_LONE_CALL = 1, 2, 3, 4, 5, 6, 7
 NMOM = 11
 
 _dp = C.POINTER(C.c_double)

@@ -67,7 +67,7 @@ struct pocs_ctx {
   std::vector<double> boxes;             // M x 5
   bool have_obstacles = false;           // pocs_set_obstacles / addObstacle / clearObstacles was called at least once
   long long shard_first = -1, shard_count = -1;
-  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0;
+  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0, opt_lone = 1;
   unsigned long long epoch = 0;          // bumped by every setter; part of the graph cache key
   int batch = 1;                         // independent GMM estimations advanced in lockstep per call
   // run-ahead (POCS_OPT_RUN_AHEAD): with batch == 1 a run* call evaluates the next `run_ahead` runs
@@ -468,7 +468,7 @@ int gmm_prepare(pocs_ctx* c) {
     if (int r = ensure(c, c->d_moments, W * R * K * POCS_NMOM * sizeof(double))) return r;
   if (c->ext_moments && c->ext_moments_len < (long long)(W * R * K * POCS_NMOM))
     return fail(c, POCS_E_BUFFER, "bound moments buffer too small");
-  if (int r = ensure(c, c->d_partial, (R << geo.vs_shift) * K * POCS_NMOM * sizeof(double))) return r;
+  if (int r = ensure(c, c->d_partial, 2 * (R << geo.vs_shift) * K * POCS_NMOM * sizeof(double))) return r;   // (x 2: a lone call alternates halves)
   if (int r = ensure(c, c->d_ticket, sync_words(c) * sizeof(unsigned))) return r;
   if (c->opt_store) {
     const size_t n = R * (size_t)sample_stride_of(count);
@@ -569,6 +569,7 @@ void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long
   a->param = (double*)c->d_param.p;
   a->moments = moments_dev(c);
   a->partial = (double*)c->d_partial.p;
+  a->partial_prev = a->partial;
   a->sync = (unsigned*)c->d_ticket.p;
   a->ticket = a->sync + sync_ticket_offset(c);
   const GmmGeometry geo = gmm_geometry(count, run_cnt, c->K, groups);
@@ -592,12 +593,29 @@ int enqueue_advance(pocs_ctx* c, int w) {
   return POCS_OK;
 }
 
+// One run per call (no batch, no run-ahead) on one GPU: the launches close the previous waypoint in their heads
+// (k_gmm_step, "LONE"): 30.6 -> 27.5 us per waypoint at 10^6 samples, K = 3 (MI355X).  POCS_OPT_LONE_CALL = 0 (or
+// POCS_LONE=0 in the environment, for A/B runs) keeps the ticket-and-closer form; the results are the same bits.
+bool lone_call(const pocs_ctx* c) {
+  static int allowed = -1;
+  if (allowed < 0) { const char* e = getenv("POCS_LONE"); allowed = (e && atoi(e) == 0) ? 0 : 1; }
+  return allowed && c->opt_lone && c->batch == 1 && !c->ext_moments;
+}
+void set_lone(pocs_ctx* c, pocs_gmm_launch* a, int w) {
+  const size_t half = ((size_t)1 << a->vs_shift) * c->K * POCS_NMOM;      // one run's rows
+  a->lone = 1;
+  a->advance_in_tail = 0;
+  a->partial = (double*)c->d_partial.p + (size_t)(w & 1) * half;
+  a->partial_prev = (double*)c->d_partial.p + (size_t)((w + 1) & 1) * half;
+}
+
 int enqueue_step(pocs_ctx* c, long long first, long long count, int w, bool advance_in_tail, int prof_slot,
-                 hipStream_t stream = nullptr, int run_lo = 0, int run_cnt = -1, int groups = 1) {
+                 hipStream_t stream = nullptr, int run_lo = 0, int run_cnt = -1, int groups = 1, bool lone = false) {
   pocs_gmm_launch a;
   if (!stream) stream = c->stream;
   fill_gmm_launch(c, &a, first, count, w, run_lo, run_cnt, groups);
   a.advance_in_tail = (advance_in_tail && w + 1 < c->W) ? 1 : 0;
+  if (lone) set_lone(c, &a, w);
   if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot], stream));
   HIPCHK(c, pocs_launch_gmm_step(c->K, a, stream));
   if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot + 1], stream));
@@ -643,11 +661,18 @@ int enqueue_gmm_all(pocs_ctx* c, long long first, long long count, bool prof) {
   if (prof) HIPCHK(c, hipEventRecord(c->ev_seq[0], c->stream));
   if (G > 1) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   for (int g = 1; g < G; ++g) HIPCHK(c, hipStreamWaitEvent(c->side_stream[g - 1], c->ev_fork, 0));
+  const bool lone = lone_call(c);
   for (int w = 0; w < W; ++w)
     for (int g = 0; g < G; ++g) {                    // sub-batch g = runs [g R / G, (g + 1) R / G); events bracket sub-batch 0's launches
       const int lo = (int)((long long)g * R / G), hi = (int)((long long)(g + 1) * R / G);
-      if (int r = enqueue_step(c, first, count, w, true, (prof && g == 0) ? w : -1, g == 0 ? c->stream : c->side_stream[g - 1], lo, hi - lo, G)) return r;
+      if (int r = enqueue_step(c, first, count, w, true, (prof && g == 0) ? w : -1, g == 0 ? c->stream : c->side_stream[g - 1], lo, hi - lo, G, lone)) return r;
     }
+  if (lone) {                                        // the last waypoint's rows -> moments[W-1]
+    pocs_gmm_launch a;
+    fill_gmm_launch(c, &a, first, count, W - 1, 0, 1, 1);
+    set_lone(c, &a, W - 1);
+    HIPCHK(c, pocs_launch_gmm_close(c->K, a, c->stream));
+  }
   for (int g = 1; g < G; ++g) {
     HIPCHK(c, hipEventRecord(c->ev_join[g - 1], c->side_stream[g - 1]));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[g - 1], 0));
@@ -705,8 +730,8 @@ void gmm_combine(pocs_ctx* c, const double* moments, double* probability) {
 
 std::string config_key(const pocs_ctx* c, long long first, long long count, const char* tag) {
   char buf[256];
-  snprintf(buf, sizeof buf, "%s e%llu W%d K%d R%d g%d n%lld f%lld c%lld s%lld fu%lld st%p em%p", tag, c->epoch,
-           c->W, c->K, c->batch, gmm_groups(c), c->num_gmm, first, count, c->opt_store, c->opt_fused,
+  snprintf(buf, sizeof buf, "%s e%llu W%d K%d R%d g%d l%d n%lld f%lld c%lld s%lld fu%lld st%p em%p", tag, c->epoch,
+           c->W, c->K, c->batch, gmm_groups(c), lone_call(c) ? 1 : 0, c->num_gmm, first, count, c->opt_store, c->opt_fused,
            (void*)c->stream, (void*)c->ext_moments);
   return buf;
 }
@@ -1138,6 +1163,7 @@ int pocs_set_option(pocs_ctx* c, int option, long long value) {
       // waypoint at every batch size measured, and not worth a second summation shape
       if (value) return fail(c, POCS_E_ARG, "POCS_OPT_PERSISTENT: the queue-driven kernel has been retired (DESIGN.md section 5)");
       break;
+    case POCS_OPT_LONE_CALL: c->opt_lone = value ? 1 : 0; break;
     case POCS_OPT_RUN_AHEAD:
       if (value < 0 || value > 256) return fail(c, POCS_E_ARG, "run-ahead %lld outside 0..256", value);
       c->run_ahead = (int)value;                     // 0 = sized per call (ra_depth)

@@ -88,6 +88,7 @@ struct pocs_gmm_launch {
   double* param;                 // [nruns][W][K*POCS_PARAM_STRIDE]  its sampler parameters (incl. the cumulative component counts)
   double* moments;               // [W][nruns][K*POCS_NMOM]          reduced moments of each waypoint
   double* partial;               // [nruns][VS][K*POCS_NMOM]         row of (run, virtual slice); rewritten every waypoint
+  const double* partial_prev;    // lone call: the rows the PREVIOUS waypoint's launch left (the other half of the buffer)
   unsigned* sync;                // the call's synchronisation words, zeroed once per call:
                                  // [1] give-up code of a bounded wait (0 = none)
   unsigned* ticket;              // [nruns][W] arrival counters of the blocks of (run, waypoint); same zeroed block
@@ -105,6 +106,8 @@ struct pocs_gmm_launch {
   int store;
   int advance_in_tail;           // 1: the last block also builds state/param[waypoint+1] (single GPU)
   int exchange_in_tail;          // 1: ... after exchanging the run's moments with the other ranks through `xchg` (sharded)
+  int lone;                      // 1: one run per call -- no tickets, no closer: every block of waypoint w's launch adds the
+                                 //    rows of w-1 and advances the mixture itself, in its head (k_gmm_step, "lone call")
   pocs_xchg_dev xchg;
   // launch geometry (above)
   long long chunks;              // of the shard
@@ -136,6 +139,7 @@ struct pocs_mc_launch {               // blockIdx.y = run of the batch, like poc
 
 hipError_t pocs_launch_gmm_step(int K, const pocs_gmm_launch& a, hipStream_t s);              // grid = a.blocks
 hipError_t pocs_launch_gmm_advance(int K, const pocs_gmm_launch& a, hipStream_t s);
+hipError_t pocs_launch_gmm_close(int K, const pocs_gmm_launch& a, hipStream_t s);             // lone call: the last waypoint's rows -> moments
 hipError_t pocs_launch_gmm_exchange(int K, const pocs_gmm_launch& a, const pocs_xchg_dev& x, hipStream_t s);   // grid = a.nruns
 hipError_t pocs_launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);
 hipError_t pocs_launch_fill(void* dst, long long bytes, hipStream_t s);

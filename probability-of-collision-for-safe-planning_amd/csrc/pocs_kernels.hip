@@ -146,8 +146,9 @@ __device__ __forceinline__ void acquire_agent() {
 }
 
 #if defined(POCS_STAMPS)       // diagnostic build (tools/stamps.sh): where the blocks of a k_gmm_step launch spend their time
-__device__ unsigned long long g_stamps[24];
-#define POCS_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_stamps[i], n_ - last_); last_ = n_; } } while (0)
+__device__ unsigned long long g_stamps[24 * 256];            // a set per block (modulo 256): blocks in lockstep must not queue on one word
+#define POCS_STAMP_AT(i) (&g_stamps[(i) + 24 * (blockIdx.x & 255)])
+#define POCS_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(POCS_STAMP_AT(i), n_ - last_); last_ = n_; } } while (0)
 #else
 #define POCS_STAMP(i) do { } while (0)
 #endif
@@ -277,7 +278,7 @@ __device__ __forceinline__ void advance_stage(const pocs_gmm_launch& a, int K, i
 // one wave, after advance_stage (+ barrier): one component per lane
 __device__ __forceinline__ void advance_components(const pocs_gmm_launch& a, int K, int w, int r, int lane, double* scratch) {
   const adv_ptrs p = advance_ptrs(a, K, w, r, scratch);
-#if defined(POCS_STAMPS)
+#if defined(POCS_STAMPS) && defined(POCS_STAMPS_PIECES)
   if (lane < K && w > 0) {
     // the pieces of pocs_gmm_advance_component with the cycle counter read between them (alive components only)
     const int k = lane;
@@ -289,7 +290,7 @@ __device__ __forceinline__ void advance_components(const pocs_gmm_launch& a, int
     for (int i = 0; i < POCS_NMOM; ++i) mom[i] = p.l_mom[k * POCS_NMOM + i];
     double keepalive = pv[13];
     asm volatile("" : "+v"(keepalive));
-#define CYC(i) do { c1 = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_stamps[i], c1 - c0); c0 = c1; } while (0)
+#define CYC(i) do { c1 = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(POCS_STAMP_AT(i), c1 - c0); c0 = c1; } while (0)
     CYC(16);
     int ok = pocs_truncated_moments(mom, tm, tc);
     asm volatile("" : "+v"(tc[8]), "+v"(tm[2]));
@@ -331,7 +332,7 @@ __device__ __forceinline__ void speculate_counts(const pocs_gmm_launch& a, int K
 // the wave of advance_components, after it (+ barrier): weights, component counts (the speculated ones
 // if there are any and their premise held), write-through stores of state[w] / param[w], drained.
 __device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, int w, int r, int lane, double* scratch,
-                                               const double* spec) {
+                                               const double* spec, const bool publish = true) {
   const adv_ptrs p = advance_ptrs(a, K, w, r, scratch);
   if (lane == 0) {
     bool use_spec = spec != nullptr;
@@ -345,29 +346,35 @@ __device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, 
   }
   __threadfence_block();
   __builtin_amdgcn_wave_barrier();
+  if (!publish) return;                              // (lone call: one block of the launch writes the records out)
   for (int j = lane; j < p.ss; j += 64) store_wt(&p.g_state[(size_t)w * p.ss + j], p.l_next[j]);
   for (int j = lane; j < p.ps; j += 64) store_wt(&p.g_param[(size_t)w * p.ps + j], p.l_par[j]);
   drain_stores();
 }
 
 // The whole advance to waypoint w by a block of >= 128 threads (every thread calls it).
+// staged: the caller has issued advance_stage already (and a barrier since); publish: state[w] / param[w] go out
+// to global memory as well (always, except for all but one block of a lone call's launch).
 __device__ __forceinline__ void advance_block(const pocs_gmm_launch& a, int K, int w, int r, double* adv, double* spec,
-                                              bool mom_in_lds, int tid, int nthreads) {
+                                              bool mom_in_lds, int tid, int nthreads, const bool staged = false,
+                                              const bool publish = true) {
 #if defined(POCS_STAMPS)
   unsigned long long t_ = wall_clock64();
-#define POCS_ADV_STAMP(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_stamps[i], n_ - t_); t_ = n_; } } while (0)
+#define POCS_ADV_STAMP(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(POCS_STAMP_AT(i), n_ - t_); t_ = n_; } } while (0)
 #else
 #define POCS_ADV_STAMP(i) do { } while (0)
 #endif
-  advance_stage(a, K, w, r, adv, mom_in_lds, tid, nthreads);
-  __syncthreads();
+  if (!staged) {
+    advance_stage(a, K, w, r, adv, mom_in_lds, tid, nthreads);
+    __syncthreads();
+  }
   POCS_ADV_STAMP(8);
   if (tid < 64) advance_components(a, K, w, r, tid, adv);
   else if (tid == 64 && w > 0) speculate_counts(a, K, w, r, adv, spec);
   POCS_ADV_STAMP(9);
   __syncthreads();
   POCS_ADV_STAMP(10);
-  if (tid < 64) advance_finish(a, K, w, r, tid, adv, w > 0 ? spec : nullptr);
+  if (tid < 64) advance_finish(a, K, w, r, tid, adv, w > 0 ? spec : nullptr, publish);
   POCS_ADV_STAMP(11);
 }
 __global__ __launch_bounds__(128) void k_gmm_advance(pocs_gmm_launch a, int K) {
@@ -863,10 +870,11 @@ __device__ __forceinline__ void gmm_emit_rows(const pocs_gmm_launch& a, gmm_smem
 // leaves the launch at the kernel boundary).
 template <int K>
 __device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const int w, const int r, const double* s_par,
-                                               double* stage, double* tot, const int tid, const int nthreads) {
+                                               double* stage, double* tot, const int tid, const int nthreads,
+                                               const double* rows, const bool store) {
   constexpr int NC = K * POCS_NMOM, G = 16;
   const int S = 1 << a.vs_shift;
-  const double* src = a.partial + (size_t)r * S * NC;
+  const double* src = rows + (size_t)r * S * NC;
   for (int i = tid; i < G * NC; i += nthreads) {
     const int g = i / NC, c = i - g * NC;
     // the item's (up to) sixteen rows g, g + 16, ... are all requested before the first is waited for -- ONE
@@ -898,7 +906,7 @@ __device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const i
     tot[k * POCS_NMOM + 1] = n_k - tot[k * POCS_NMOM];
   }
   __syncthreads();
-  for (int c = tid; c < NC; c += nthreads) a.moments[((size_t)w * a.nruns + r) * NC + c] = tot[c];
+  if (store) for (int c = tid; c < NC; c += nthreads) a.moments[((size_t)w * a.nruns + r) * NC + c] = tot[c];
 }
 
 // One waypoint of runs [run_lo, run_lo + run_cnt) of the call as ONE launch (the host issues a call's runs as
@@ -915,7 +923,17 @@ __device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const i
 //   tail  every storing wave drains -> the block meets -> one ticket per run it touched; the block that
 //         draws a run's last ticket acquires, adds the run's VS rows and (one GPU) advances the mixture
 //         to the next waypoint -- sharded: after exchanging the run's moments with the other ranks.
-template <int K, bool STORE, int TB>
+//
+// LONE (one run per call, no batch, no run-ahead): nothing else is in flight to hide a closer behind, and the
+// tickets' two round trips (drain the rows, draw the ticket) and the closer's acquire are pure latency.  The
+// launch of waypoint w then closes waypoint w - 1 ITSELF, in the head of EVERY block: the rows of w - 1 (the
+// other half of the row buffer: a fast block must not overwrite what a slow one still reads), state[w-1] and
+// the chain record arrive in one round trip behind the kernel boundary; every block adds the rows in the
+// fixed order, advances the mixture -- 256 times the same few microseconds of one wave, on CUs that would
+// otherwise wait for one of them to do it -- and keeps param[w] in LDS; block 0 writes moments[w-1], state[w],
+// param[w] out for the getters.  The tail is the rows' stores and nothing else; a one-block launch
+// (k_gmm_close) adds the last waypoint's rows.  Same functions, same order of additions: the same bits.
+template <int K, bool STORE, int TB, bool LONE>
 __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_step(pocs_gmm_launch a) {
   typedef gmm_smem<K, TB> smem_t;
   constexpr int NC = smem_t::NC, SUB = smem_t::SUB, NW = smem_t::NW;
@@ -929,15 +947,37 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   const int r0 = t0 >> a.vs_shift, r1 = (t1 - 1) >> a.vs_shift;       // the block's first and last run (r1 <= r0 + 1)
 #if defined(POCS_STAMPS)
   unsigned long long last_ = wall_clock64();
-  if (tid == 0) atomicAdd(&g_stamps[15], 1ull);
+  if (tid == 0) atomicAdd(POCS_STAMP_AT(15), 1ull);
 #endif
   stage_tables(a.tables, &sm.tab);
-  for (int j = tid; j < a.M * POCS_OBS_STRIDE; j += TB) sm.obs()[j] = a.env->obs[j];
-  for (int j = tid; j < (r1 - r0 + 1) * K * POCS_PARAM_STRIDE; j += TB)   // param[r][w][..]: the two runs' records are a.W records apart
-    sm.par[j / (K * POCS_PARAM_STRIDE)][j % (K * POCS_PARAM_STRIDE)] =
-        load_wt(&a.param[((size_t)(r0 + j / (K * POCS_PARAM_STRIDE)) * a.W + w) * (K * POCS_PARAM_STRIDE) + j % (K * POCS_PARAM_STRIDE)]);
-  for (int j = tid; j < 2 * NW * K; j += TB) (&sm.xj[0][0][0])[j] = -1;
-  if (tid <= r1 - r0) sm.seed[tid] = a.hdr[r0 + tid].seed;
+  if (LONE && w > 0) {
+    // close waypoint w - 1 and advance to w, here (r0 is the call's one run)
+    constexpr int PS = K * POCS_PARAM_STRIDE;
+    const bool out = blockIdx.x == 0;
+    advance_stage(a, K, w, r0, sm.adv(), true, tid, TB);                                   // loads in flight ...
+    for (int j = tid; j < PS; j += TB) sm.par[1][j] = a.param[((size_t)r0 * a.W + (w - 1)) * PS + j];   // (the counts of w - 1)
+    for (int j = tid; j < 2 * NW * K; j += TB) (&sm.xj[0][0][0])[j] = -1;
+    if (tid == 0) sm.seed[0] = a.hdr[r0].seed;
+    double* const l_mom = advance_ptrs(a, K, w, r0, sm.adv()).l_mom;
+    gmm_close_sums<K>(a, w - 1, r0, sm.par[1], sm.stage(), l_mom, tid, TB, a.partial_prev, out);   // ... with the rows'
+    POCS_STAMP(5);
+    advance_block(a, K, w, r0, sm.adv(), sm.spec(), true, tid, TB, true, out);
+    __syncthreads();
+    POCS_STAMP(6);
+#if defined(POCS_STAMPS)
+    if (tid == 0) atomicAdd(POCS_STAMP_AT(14), 1ull);
+#endif
+    const double* const l_par = advance_ptrs(a, K, w, r0, sm.adv()).l_par;
+    for (int j = tid; j < PS; j += TB) sm.par[0][j] = l_par[j];
+    for (int j = tid; j < a.M * POCS_OBS_STRIDE; j += TB) sm.obs()[j] = a.env->obs[j];     // (the staging rows are done with)
+  } else {
+    for (int j = tid; j < a.M * POCS_OBS_STRIDE; j += TB) sm.obs()[j] = a.env->obs[j];
+    for (int j = tid; j < (r1 - r0 + 1) * K * POCS_PARAM_STRIDE; j += TB)   // param[r][w][..]: the two runs' records are a.W records apart
+      sm.par[j / (K * POCS_PARAM_STRIDE)][j % (K * POCS_PARAM_STRIDE)] =
+          load_wt(&a.param[((size_t)(r0 + j / (K * POCS_PARAM_STRIDE)) * a.W + w) * (K * POCS_PARAM_STRIDE) + j % (K * POCS_PARAM_STRIDE)]);
+    for (int j = tid; j < 2 * NW * K; j += TB) (&sm.xj[0][0][0])[j] = -1;
+    if (tid <= r1 - r0) sm.seed[tid] = a.hdr[r0 + tid].seed;
+  }
   __syncthreads();
   if (tid < 64) gmm_cull(a, sm, 0, tid);
   else if (tid < 128 && r1 > r0) gmm_cull(a, sm, 1, tid - 64);
@@ -956,6 +996,7 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
       __syncthreads();
     }
   }
+  if (LONE) return;                                  // the rows leave through the kernel boundary; the next launch's heads add them
   drain_stores();
   __syncthreads();
   POCS_STAMP(3);
@@ -978,7 +1019,7 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
     if (tid == 0) acquire_agent();
     __syncthreads();
     double* const l_mom = advance_ptrs(a, K, w + 1, r, sm.adv()).l_mom;
-    gmm_close_sums<K>(a, w, r, sm.par[rb], sm.stage(), l_mom, tid, TB);
+    gmm_close_sums<K>(a, w, r, sm.par[rb], sm.stage(), l_mom, tid, TB, a.partial, true);
     POCS_STAMP(5);
     if (a.exchange_in_tail) {
       // sharded: the run's closer is also its messenger -- this shard's moments go to every rank, the world's
@@ -991,13 +1032,25 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
     __syncthreads();
     POCS_STAMP(6);
 #if defined(POCS_STAMPS)
-    if (tid == 0) atomicAdd(&g_stamps[14], 1ull);
+    if (tid == 0) atomicAdd(POCS_STAMP_AT(14), 1ull);
 #endif
     return true;
   };
   const int last0 = __builtin_amdgcn_readfirstlane(sm.last[0]), last1 = __builtin_amdgcn_readfirstlane(sm.last[1]);
   if (last0 && !closer(0)) return;
   if (last1) (void)closer(1);
+}
+
+// Lone call, behind the last waypoint's launch: its rows -> moments[W-1] (one block).
+template <int K>
+__global__ __launch_bounds__(256) void k_gmm_close(pocs_gmm_launch a) {
+  constexpr int NC = K * POCS_NMOM, PS = K * POCS_PARAM_STRIDE;
+  __shared__ double s_par[PS];
+  __shared__ double s_stage[16 * NC];
+  __shared__ double s_tot[NC];
+  const int w = a.waypoint, r = a.run_lo;
+  for (int j = threadIdx.x; j < PS; j += 256) s_par[j] = a.param[((size_t)r * a.W + w) * PS + j];
+  gmm_close_sums<K>(a, w, r, s_par, s_stage, s_tot, threadIdx.x, 256, a.partial, true);    // (first barrier: s_par is in)
 }
 
 // MC kernels: blockIdx.y = run of the batch (its own seed, its own noisy controls, its own slice
@@ -1134,8 +1187,18 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_count(pocs_mc_launch a) {
 template <int K>
 hipError_t launch_gmm_k(const pocs_gmm_launch& a, hipStream_t s) {
   constexpr int TB = POCS_GMM_BLOCK_OF(K);
-  if (a.store) hipLaunchKernelGGL((k_gmm_step<K, true, TB>), dim3(a.blocks), dim3(TB), 0, s, a);
-  else         hipLaunchKernelGGL((k_gmm_step<K, false, TB>), dim3(a.blocks), dim3(TB), 0, s, a);
+  if (a.lone) {
+    if (a.store) hipLaunchKernelGGL((k_gmm_step<K, true, TB, true>), dim3(a.blocks), dim3(TB), 0, s, a);
+    else         hipLaunchKernelGGL((k_gmm_step<K, false, TB, true>), dim3(a.blocks), dim3(TB), 0, s, a);
+  } else {
+    if (a.store) hipLaunchKernelGGL((k_gmm_step<K, true, TB, false>), dim3(a.blocks), dim3(TB), 0, s, a);
+    else         hipLaunchKernelGGL((k_gmm_step<K, false, TB, false>), dim3(a.blocks), dim3(TB), 0, s, a);
+  }
+  return hipGetLastError();
+}
+template <int K>
+hipError_t launch_gmm_close_k(const pocs_gmm_launch& a, hipStream_t s) {
+  hipLaunchKernelGGL((k_gmm_close<K>), dim3(1), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -1143,8 +1206,11 @@ hipError_t launch_gmm_k(const pocs_gmm_launch& a, hipStream_t s) {
 
 #if defined(POCS_STAMPS)
 extern "C" void pocs_stamps_report() {
-  unsigned long long h[24];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) != hipSuccess || h[15] == 0) return;
+  static unsigned long long all[24 * 256];
+  unsigned long long h[24] = {0};
+  if (hipMemcpyFromSymbol(all, HIP_SYMBOL(g_stamps), sizeof all) != hipSuccess) return;
+  for (int b = 0; b < 256; ++b) for (int i = 0; i < 24; ++i) h[i] += all[24 * b + i];
+  if (h[15] == 0) return;
   const double nb = (double)h[15], nc = (double)(h[14] ? h[14] : 1);
   fprintf(stderr, "[stamps] %.0f blocks, %.0f closers; per block (us): head %.2f | units %.2f | -> barrier %.2f | rows + drain + barrier %.2f | "
           "ticket + barrier %.2f ; per closer: close_sums %.2f | advance %.2f (staging %.2f, components (wave 0) %.2f, -> the counts lane %.2f, normalise + publish + drain %.2f)\n",
@@ -1152,10 +1218,24 @@ extern "C" void pocs_stamps_report() {
           0.01 * h[8] / nc, 0.01 * h[9] / nc, 0.01 * h[10] / nc, 0.01 * h[11] / nc);
   fprintf(stderr, "[stamps] a component done a second time, in pieces (cycles per closer): LDS reads %.0f | truncated moments %.0f | predict %.0f | update %.0f | chol %.0f\n",
           (double)h[16] / nc, (double)h[17] / nc, (double)h[18] / nc, (double)h[19] / nc, (double)h[20] / nc);
-  unsigned long long z[24] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
+  for (auto& v : all) v = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), all, sizeof all);
 }
 #endif
+
+hipError_t pocs_launch_gmm_close(int K, const pocs_gmm_launch& a, hipStream_t s) {
+  switch (K) {
+    case 1: return launch_gmm_close_k<1>(a, s);
+    case 2: return launch_gmm_close_k<2>(a, s);
+    case 3: return launch_gmm_close_k<3>(a, s);
+    case 4: return launch_gmm_close_k<4>(a, s);
+    case 5: return launch_gmm_close_k<5>(a, s);
+    case 6: return launch_gmm_close_k<6>(a, s);
+    case 7: return launch_gmm_close_k<7>(a, s);
+    case 8: return launch_gmm_close_k<8>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
 
 hipError_t pocs_launch_gmm_step(int K, const pocs_gmm_launch& a, hipStream_t s) {
   switch (K) {

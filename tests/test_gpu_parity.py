@@ -229,6 +229,28 @@ def test_runs_per_launch_do_not_change_a_bit(pocs, plan, env, K, N, R):
                 assert np.array_equal(f, singles[r][3][1]) and np.array_equal(x, singles[r][3][0]), (rep, r)
 
 
+@pytest.mark.parametrize("K,N", [(3, 300000), (8, 150000), (1, 1_000_001), (2, 3001)])
+def test_lone_call_changes_no_bit(pocs, orc, plan, env, K, N):
+    """One run per call has a launch form of its own (POCS_OPT_LONE_CALL, the default: every block of waypoint w's
+    launch adds the rows of w - 1 and advances the mixture in its head; no tickets, no closing block).  Against the
+    ticket form, replayed from a graph and launched eagerly, twice over: moments, probabilities, mixture states of
+    all 56 waypoints, the last waypoint's samples and flags -- and the oracle's probabilities."""
+    with pocs.Context(0) as c:
+        c.configure(plan, env, K=K, N=N, seed=77)
+        outs = []
+        for lone, graph in ((1, 1), (0, 1), (1, 0), (0, 0), (1, 1)):
+            c.set_option(pocs.OPT_LONE_CALL, lone)
+            c.set_option(pocs.OPT_USE_GRAPH, graph)
+            c.set_seed(77)
+            p = c.run_gmm_estimation()
+            outs.append((np.float64(p),) + _run_of_batch(c, 0, K, 56) + tuple(c.gmm_samples(N)))
+        for i, o in enumerate(outs[1:]):
+            assert all(np.array_equal(a, b) for a, b in zip(o, outs[0])), i + 1
+    if N <= 300000:
+        want = orc.run_gmm(orc.config(plan, env, K=K), 77, N)
+        assert outs[0][0] == want["prob"] and np.array_equal(outs[0][2], want["probs"])
+
+
 def test_gmm_variants_agree(ctx, pocs, plan, env):
     """Graph replay vs eager launches, with and without the sample store, with the profiling events,
     and the per-waypoint step API: the same units with the same arithmetic, so everything is bitwise

@@ -53,7 +53,7 @@ def mem_ops(ops, prefix):
     return [o for o in ops if o.startswith(prefix)]
 
 
-@pytest.mark.parametrize("sub,streaming_bits", [("k_gmm_stepILi3ELb1ELi512", "nt"), ("k_gmm_stepILi8ELb1ELi512", "nt")])
+@pytest.mark.parametrize("sub,streaming_bits", [("k_gmm_stepILi3ELb1ELi512ELb0E", "nt"), ("k_gmm_stepILi8ELb1ELi512ELb0E", "nt")])
 def test_gmm_kernel_handoff_shapes(listing, sub, streaming_bits):
     ops = kernel(listing, sub)
     stores = mem_ops(ops, "global_store")
@@ -102,3 +102,15 @@ def test_advance_kernel_publishes_write_through(listing):
     ops = kernel(listing, "k_gmm_advance")
     stores = mem_ops(ops, "global_store")
     assert stores and all("sc1" in o.split() for o in stores), stores
+
+
+@pytest.mark.parametrize("sub", ["k_gmm_stepILi3ELb1ELi512ELb1E", "k_gmm_stepILi8ELb0ELi512ELb1E"])
+def test_lone_form_has_no_handoff_inside_the_launch(listing, sub):
+    """The launch form of a lone call (one run per call) hands nothing from block to block INSIDE a launch: the rows
+    and the records leave through the kernel boundary and the next launch reads them behind it.  So: no ticket
+    atomic, no agent-scope acquire, no spin -- whatever a compiler update does to the stores' cache bits."""
+    ops = kernel(listing, sub)
+    assert not [o for o in ops if o.startswith("global_atomic")], "an atomic in the lone form"
+    assert not [o for o in ops if o.startswith("buffer_inv")], "an acquire in the lone form"
+    assert not mem_ops(ops, "flat_"), "flat accesses in a GMM kernel"
+    assert not [o for o in ops if o.startswith("s_sleep")], "a wait loop in the lone form"
