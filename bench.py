@@ -398,7 +398,8 @@ def main():
             # skew tolerance: a second batch of runs in flight on a stream of its own -- while one
             # engine's closers wait for the slowest rank's moments, the other engine's sampling blocks have the chip
             n_eng = 2
-        made = [make(b_hi, 0x5EED0001 + i, torch.cuda.Stream() if n_eng > 1 else None) for i in range(n_eng)]
+        # (every engine on a torch stream of its own: its launches, its collectives and its event waits in one order)
+        made = [make(b_hi, 0x5EED0001 + i, torch.cuda.Stream()) for i in range(n_eng)]
         ctx = made[0][0]
         engines = [e for _, e in made]
         # POCS_ONEHOP=1: the library's own exchange (IPC-mapped slots, one hop over xGMI, sum + mixture

@@ -108,7 +108,11 @@ int pocs_select_batch_run(pocs_ctx* ctx, int run);   /* the getters below (waypo
  * A context evaluates global sample / particle indices [first, first+count) of the N configured;
  * random draws are keyed by the GLOBAL index so results do not depend on the partition. */
 int pocs_set_shard(pocs_ctx* ctx, long long first, long long count);   /* (-1, -1) = the whole range again */
-int pocs_set_stream(pocs_ctx* ctx, void* hip_stream);                 /* launch on this stream (e.g. torch's current stream) */
+int pocs_set_stream(pocs_ctx* ctx, void* hip_stream);                 /* launch on this stream (e.g. a torch stream).  NULL = back to the context's
+                                                                          own NON-BLOCKING stream -- not the null stream: a caller whose
+                                                                          other work (collectives, copies) runs on the null stream -- torch's
+                                                                          default "current stream" has handle 0 -- passes hipStreamLegacy
+                                                                          ((hipStream_t)1), or the two are not ordered (parallel.GpuEngine does) */
 
 /* GMM, one waypoint at a time: begin -> for w in 0..W-1 { step_local(w); <all-reduce SUM of
  * moments_ptr(w), moments_len doubles>; } -> end.  step_local(w) first folds the (already

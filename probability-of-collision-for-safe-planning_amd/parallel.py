@@ -12,6 +12,8 @@ Random draws are keyed by the GLOBAL sample index, so the result does not depend
 """
 import numpy as np
 
+HIP_STREAM_LEGACY = 1          # hipStreamLegacy ((hipStream_t)1), hip_runtime_api.h: the null stream, by name
+
 
 def shard_range(n_total, rank, world):
     """Contiguous, balanced split of range(n_total): returns (first, count) of `rank`.
@@ -153,8 +155,12 @@ class GpuEngine:
         first, count = (rank * per_rank, per_rank) if per_rank else shard_range(n_total, rank, world)
         ctx.set_shard(first, count)
         self.count = count
-        # launch on a torch stream so kernels and collectives are ordered without host syncs
-        ctx.set_stream((stream or torch.cuda.current_stream()).cuda_stream)
+        # launch on a torch stream so kernels and collectives are ordered without host syncs.  torch's default
+        # "current stream" is the null stream, whose handle is 0 -- which pocs_set_stream reads as "the context's
+        # own (non-blocking) stream": name the null stream by hipStreamLegacy instead, or the caller's collectives
+        # on the current stream would not be ordered with the context's launches at all.
+        handle = (stream or torch.cuda.current_stream()).cuda_stream
+        ctx.set_stream(handle if handle else HIP_STREAM_LEGACY)
         self.buf = torch.zeros(W * batch * K * 11, dtype=torch.float64, device="cuda")   # [W][batch][K*11]
         ctx.gmm_bind_moments(self.buf.data_ptr(), self.buf.numel())
         torch.cuda.synchronize()               # the zero fill ran on torch's default stream
