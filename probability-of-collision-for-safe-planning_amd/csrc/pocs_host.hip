@@ -197,7 +197,10 @@ int grid_blocks(long long count, int block, int default_bpc) {
 // fatter blocks amortise head and tail better when the launch is short anyway), so every block of a launch
 // has the same amount of work whatever the number of runs (20 runs x 256 slices = 512 blocks x 10).
 // POCS_GMM_BLOCKS overrides the block budget for sweeps.
-struct GmmGeometry { long long chunks; int vs_shift; int upb; int blocks; };
+#ifndef POCS_GMM_SKEW_DEFAULT
+#define POCS_GMM_SKEW_DEFAULT 500
+#endif
+struct GmmGeometry { long long chunks; int vs_shift; int upb; int upb2; int split; int blocks; };
 GmmGeometry gmm_geometry(long long count, int runs, int K, int groups = 1) {
   static int forced = -1;
   if (forced < 0) {
@@ -220,6 +223,30 @@ GmmGeometry gmm_geometry(long long count, int runs, int K, int groups = 1) {
   g.upb = (int)((units + budget - 1) / budget);
   if (g.upb > (1 << g.vs_shift)) g.upb = 1 << g.vs_shift;           // a block's range touches at most two runs
   g.blocks = (int)((units + g.upb - 1) / g.upb);
+  g.upb2 = g.upb; g.split = g.blocks;
+  // Two blocks per CU: the chip places blocks 0..255 first and 256..511 beside them, and a SIMD's arbiter prefers
+  // its OLDER waves whenever priorities tie -- measured (per-block stamps, 10^6 samples, K = 3), the second half of
+  // the grid needs 14 % longer for the same units at 20 runs per launch and 17 % at 64, launch after launch, and the
+  // launch ends with the slowest block.  So the halves get unequal shares: the first 256 blocks `upb` units each,
+  // the rest `upb2`, in the ratio of their measured paces (POCS_GMM_SKEW, per mille of a CU's units that go to its
+  // first block; 500 = even).  Which block adds which unit changes no bit: a unit's row is the unit's alone.
+  static int skew = -1;
+  if (skew < 0) {
+    const char* e = getenv("POCS_GMM_SKEW");
+    skew = e ? atoi(e) : POCS_GMM_SKEW_DEFAULT;
+    if (skew < 500 || skew > 750) skew = 500;
+  }
+  if (!forced && groups == 1 && skew > 500 && g.blocks == POCS_NUM_CUS * 2 && units >= 4LL * POCS_NUM_CUS) {
+    const long long per_cu = (units + POCS_NUM_CUS - 1) / POCS_NUM_CUS;
+    int ua = (int)((per_cu * skew + 500) / 1000);
+    if (ua > (1 << g.vs_shift)) ua = 1 << g.vs_shift;
+    const long long rest = units - (long long)POCS_NUM_CUS * ua;
+    if (ua >= 1 && rest > 0) {
+      const int ub = (int)((rest + POCS_NUM_CUS - 1) / POCS_NUM_CUS);
+      g.upb = ua; g.upb2 = ub; g.split = POCS_NUM_CUS;
+      g.blocks = POCS_NUM_CUS + (int)((rest + ub - 1) / ub);
+    }
+  }
   return g;
 }
 int grid_for_mc(long long count, int runs = 1) {                                      // MC kernels, per run
@@ -573,7 +600,7 @@ void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long
   a->sync = (unsigned*)c->d_ticket.p;
   a->ticket = a->sync + sync_ticket_offset(c);
   const GmmGeometry geo = gmm_geometry(count, run_cnt, c->K, groups);
-  a->chunks = geo.chunks; a->vs_shift = geo.vs_shift; a->upb = geo.upb; a->blocks = geo.blocks;
+  a->chunks = geo.chunks; a->vs_shift = geo.vs_shift; a->upb = geo.upb; a->upb2 = geo.upb2; a->split = geo.split; a->blocks = geo.blocks;
   a->run_lo = run_lo; a->run_cnt = run_cnt;
   a->x = (double*)c->d_sx.p; a->y = (double*)c->d_sy.p; a->th = (double*)c->d_st.p;
   a->flags = (int16_t*)c->d_flags.p;

@@ -112,8 +112,10 @@ struct pocs_gmm_launch {
   // launch geometry (above)
   long long chunks;              // of the shard
   int vs_shift;                  // VS = 1 << vs_shift virtual slices per run
-  int upb;                       // units per block (<= VS)
-  int blocks;                    // ceil(run_cnt * VS / upb)
+  int upb;                       // units per block (<= VS) of blocks [0, split)
+  int upb2, split;               // ... and of blocks [split, blocks): the second block of a CU -- the younger one, which the
+                                 // SIMDs' age-ordered arbitration leaves behind -- gets fewer (pocs_host.hip, gmm_geometry)
+  int blocks;                    // all of them
   int run_lo, run_cnt;           // the runs of the batch this launch works on
 };
 #define POCS_SYNC_ABORT 1

@@ -148,6 +148,8 @@ __device__ __forceinline__ void acquire_agent() {
 #if defined(POCS_STAMPS)       // diagnostic build (tools/stamps.sh): where the blocks of a k_gmm_step launch spend their time
 __device__ unsigned long long g_stamps[24 * 256];            // a set per block (modulo 256): blocks in lockstep must not queue on one word
 #define POCS_STAMP_AT(i) (&g_stamps[(i) + 24 * (blockIdx.x & 255)])
+__device__ unsigned g_tn[512];                     // per block index: launches seen, and the time wave 0 spent in its units
+__device__ float g_t[512][2048];                   // in each of them (10 ns ticks): the spread WITHIN a launch
 #define POCS_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(POCS_STAMP_AT(i), n_ - last_); last_ = n_; } } while (0)
 #else
 #define POCS_STAMP(i) do { } while (0)
@@ -622,6 +624,9 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
   // one.  The second block of a CU is (observed, speed only) the one dispatched 256 blocks later.
   const int prio_slot = (TB >= 512 ? (wave >> 2) : 0) + (TB >= 512 ? 2 : 1) * (int)((blockIdx.x >> 8) & 3u);
   int prio_it = prio_slot;
+#if defined(POCS_PRIO_TIME_SHIFT)
+  unsigned prio_clk = (unsigned)(wall_clock64() >> POCS_PRIO_TIME_SHIFT);
+#endif
 #endif
   // per run (wave-uniform; reloaded when the block's range crosses into its second run)
   int rb = -1, nkeep = 0, kcur = 0, kw = 0;
@@ -646,6 +651,10 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
   auto iteration = [&](auto whole_tag, const int base, const int tl, bool& first) __attribute__((always_inline)) {
     constexpr bool WHOLE = decltype(whole_tag)::value;
 #if !defined(POCS_NO_PRIO_ROTATION)
+#if defined(POCS_PRIO_TIME_SHIFT)
+    prio_it = (int)prio_clk + prio_slot;           // by TIME: every wave of the SIMD holds every level for the same time, whatever its pace
+    prio_clk = (unsigned)(wall_clock64() >> POCS_PRIO_TIME_SHIFT);      // (for the next iteration: the read is not waited for here)
+#endif
     switch (prio_it++ & 3) {                       // s_setprio takes an immediate
       case 0: __builtin_amdgcn_s_setprio(0); break;
       case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -942,8 +951,10 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   const int w = a.waypoint;
   const int VS = 1 << a.vs_shift;
   const int t_lo = a.run_lo << a.vs_shift, t_hi = (a.run_lo + a.run_cnt) << a.vs_shift;    // this launch's units
-  const int t0 = t_lo + (int)blockIdx.x * a.upb;
-  const int t1 = (t0 + a.upb < t_hi) ? t0 + a.upb : t_hi;
+  const int bx = (int)blockIdx.x;
+  const int my_upb = bx < a.split ? a.upb : a.upb2;
+  const int t0 = t_lo + (bx < a.split ? bx * a.upb : a.split * a.upb + (bx - a.split) * a.upb2);
+  const int t1 = (t0 + my_upb < t_hi) ? t0 + my_upb : t_hi;
   const int r0 = t0 >> a.vs_shift, r1 = (t1 - 1) >> a.vs_shift;       // the block's first and last run (r1 <= r0 + 1)
 #if defined(POCS_STAMPS)
   unsigned long long last_ = wall_clock64();
@@ -986,8 +997,22 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   for (int ta = t0; ta < t1; ta += SUB) {
     const int tb = (ta + SUB < t1) ? ta + SUB : t1;
     gmm_units<K, STORE, TB>(a, sm, w, r0, ta, tb);
+#if defined(POCS_STAMPS)
+    __shared__ unsigned long long s_wend[NW];
+    if ((tid & 63) == 0) s_wend[tid >> 6] = wall_clock64();
+    const unsigned long long units_ = wall_clock64() - last_;
+#endif
     POCS_STAMP(1);
     __syncthreads();
+#if defined(POCS_STAMPS)
+    if (tid == 0) {                                  // how far apart the block's waves finish, and the blocks' spread (sum of squares)
+      unsigned long long lo = s_wend[0], hi = s_wend[0];
+      for (int u = 1; u < NW; ++u) { lo = s_wend[u] < lo ? s_wend[u] : lo; hi = s_wend[u] > hi ? s_wend[u] : hi; }
+      atomicAdd(POCS_STAMP_AT(21), hi - lo);
+      atomicAdd(POCS_STAMP_AT(22), units_ * units_);
+      if (blockIdx.x < 512) { const unsigned n = g_tn[blockIdx.x]++; if (n < 2048) g_t[blockIdx.x][n] = (float)units_; }
+    }
+#endif
     POCS_STAMP(2);
     gmm_emit_rows(a, sm, r0, ta, tb);
     if (tb < t1) {                                   // more units to come (only launches of > 64 runs): the slots start over
@@ -1002,7 +1027,8 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   POCS_STAMP(3);
   if (tid <= r1 - r0) {                              // one ticket per run touched: the blocks whose range meets [r VS, (r + 1) VS)
     const int r = r0 + tid;
-    const int b_first = ((r << a.vs_shift) - t_lo) / a.upb, b_last_raw = ((((r + 1) << a.vs_shift) - 1) - t_lo) / a.upb;
+    auto block_of = [&](const int t_rel) { return t_rel < a.split * a.upb ? t_rel / a.upb : a.split + (t_rel - a.split * a.upb) / a.upb2; };
+    const int b_first = block_of((r << a.vs_shift) - t_lo), b_last_raw = block_of((((r + 1) << a.vs_shift) - 1) - t_lo);
     const int b_last = b_last_raw < (int)gridDim.x - 1 ? b_last_raw : (int)gridDim.x - 1;
     const unsigned t = __hip_atomic_fetch_add(&a.ticket[(size_t)r * a.W + w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sm.last[tid] = (t == (unsigned)(b_last - b_first)) ? 1 : 0;
@@ -1216,6 +1242,39 @@ extern "C" void pocs_stamps_report() {
           "ticket + barrier %.2f ; per closer: close_sums %.2f | advance %.2f (staging %.2f, components (wave 0) %.2f, -> the counts lane %.2f, normalise + publish + drain %.2f)\n",
           nb, nc, 0.01 * h[0] / nb, 0.01 * h[1] / nb, 0.01 * h[2] / nb, 0.01 * h[3] / nb, 0.01 * h[4] / nb, 0.01 * h[5] / nc, 0.01 * h[6] / nc,
           0.01 * h[8] / nc, 0.01 * h[9] / nc, 0.01 * h[10] / nc, 0.01 * h[11] / nc);
+  fprintf(stderr, "[stamps] a block's waves finish %.2f us apart (first to last); units of wave 0: mean %.2f, sd over blocks %.2f us\n",
+          0.01 * h[21] / nb, 0.01 * h[1] / nb, 0.01 * sqrt(fmax(0.0, (double)h[22] / nb - ((double)h[1] / nb) * ((double)h[1] / nb))));
+  {
+    static unsigned tn[512];
+    static float tt[512][2048];
+    if (hipMemcpyFromSymbol(tn, HIP_SYMBOL(g_tn), sizeof tn) == hipSuccess && hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_t), sizeof tt) == hipSuccess) {
+      int nb_ = 0;
+      while (nb_ < 512 && tn[nb_] == tn[0] && tn[0] > 0) ++nb_;
+      const unsigned nl = tn[0] < 2048 ? tn[0] : 2048;
+      double ssd = 0, srange = 0, shalf = 0;
+      for (unsigned n = 0; n < nl; ++n) {
+        double m = 0, q = 0, lo = 1e30, hi = 0, ma = 0, mb = 0;
+        for (int b = 0; b < nb_; ++b) { const double v = tt[b][n]; m += v; q += v * v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; (b < nb_ / 2 ? ma : mb) += v; }
+        m /= nb_; ssd += sqrt(fmax(0.0, q / nb_ - m * m)); srange += hi - lo; shalf += (mb - ma) / (nb_ / 2);
+      }
+      if (nl && nb_ > 1) {
+        // is a block index slow in EVERY launch?  per-block means over the launches, by XCD (b mod 8) and by residency (b / 256)
+        double bm[512], all = 0, byx[8] = {0}, sdm = 0;
+        for (int b = 0; b < nb_; ++b) { double m = 0; for (unsigned n = 0; n < nl; ++n) m += tt[b][n]; bm[b] = m / nl; all += bm[b]; byx[b & 7] += bm[b]; }
+        all /= nb_;
+        for (int b = 0; b < nb_; ++b) sdm += (bm[b] - all) * (bm[b] - all);
+        fprintf(stderr, "[stamps] per-block means over the launches: sd %.2f us; by b mod 8 (us):", 0.01 * sqrt(sdm / nb_));
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", 0.01 * byx[x] / (nb_ / 8));
+        double lo = 1e30, hi = 0; int ilo = 0, ihi = 0;
+        for (int b = 0; b < nb_; ++b) { if (bm[b] < lo) { lo = bm[b]; ilo = b; } if (bm[b] > hi) { hi = bm[b]; ihi = b; } }
+        fprintf(stderr, "; fastest block %d %.1f, slowest %d %.1f\n", ilo, 0.01 * lo, ihi, 0.01 * hi);
+      }
+      if (nl && nb_ > 1) fprintf(stderr, "[stamps] WITHIN a launch (%d blocks, %u launches): sd of the blocks' unit times %.2f us, slowest - fastest %.2f us, second half of the grid - first half %.2f us\n",
+                                 nb_, nl, 0.01 * ssd / nl, 0.01 * srange / nl, 0.01 * shalf / nl);
+    }
+    for (auto& v : tn) v = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tn), tn, sizeof tn);
+  }
   fprintf(stderr, "[stamps] a component done a second time, in pieces (cycles per closer): LDS reads %.0f | truncated moments %.0f | predict %.0f | update %.0f | chol %.0f\n",
           (double)h[16] / nc, (double)h[17] / nc, (double)h[18] / nc, (double)h[19] / nc, (double)h[20] / nc);
   for (auto& v : all) v = 0;
