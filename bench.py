@@ -482,6 +482,21 @@ def main():
         if path == "gmm" and not engines and hasattr(ctx.lib, "pocs_get_sequence_time"):      # (an A/B library of an older commit has none)
             seq_ms, groups = ctx.sequence_time()
             waypoint_us = seq_ms * 1e3 / W
+    # the same launches WITHOUT the sample stores (POCS_OPT_STORE_SAMPLES = 0: a product option, same arithmetic, same
+    # results): what the arithmetic alone takes on this box, to set beside what the stream alone would take at the fill
+    # rate -- the two meet at the board's power cap; not part of `value`
+    nostore_ms = None
+    if path == "gmm" and not engines and os.environ.get("POCS_NO_STORE") != "1":
+        ctx.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
+        run_steps([b_hi])                            # (the graph / buffers of this variant)
+        t_ms, t_n = 0.0, 0
+        for _ in range(max(1, min(len(chunks), 2))):
+            run_steps([b_hi])
+            ms, n = ctx.kernel_time()
+            t_ms += ms
+            t_n += n
+        ctx.set_option(pocs_amd.OPT_STORE_SAMPLES, 1)
+        nostore_ms = t_ms / max(t_n, 1)
     ctx.set_option(pocs_amd.OPT_PROFILE, 0)
     # shader clock under this load, in calls of their own: a sensor read goes through the driver and
     # disturbs the GPU (kernels 15 % slower while it polls), so nothing else is measured meanwhile
@@ -532,7 +547,10 @@ def main():
     if path == "gmm":
         clock = (board or {}).get("sclk_MHz") or 2400.0
         issue_peak = 1024 * clock * 1e6 / 4.0
-        limiter = {"kind": "FP64 vector issue (+ per-lane LDS table reads) at the board's power cap, not HBM bandwidth",
+        limiter = {"kind": "FP64 vector issue (+ per-lane LDS table reads) and the all-write sample stream, coupled through the "
+                           "board's power cap: neither alone (DESIGN.md section 5)",
+                   "kernel_us_without_sample_stores": nostore_ms * 1e3 if nostore_ms else None,
+                   "stream_alone_us_at_fill_rate": (bpe * units / (fill_gbps * 1e9) * 1e6) if fill_gbps > 0 else None,
                    "valu_instr_per_eval": valu_per_eval, "clock_MHz": clock,
                    "clock_source": "amdgpu hwmon, live" if (board or {}).get("sclk_MHz") else "peak clock (no live reading)",
                    "valu_issue_frac": (valu_per_eval * (units / 64.0) / (avg_ms * 1e-3) / issue_peak) if (valu_per_eval and avg_ms > 0) else None,

@@ -58,6 +58,10 @@ def test_full_size_line_carries_the_counter_records():
     assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
     lim = r["limiter"]
     assert 100 < lim["valu_instr_per_eval"] < 200 and 0.3 < lim["valu_issue_frac"] < 1.0 and lim["clock_MHz"] > 1000
+    # the two floors that meet at the power cap: the arithmetic alone (the same launches without the sample stores) and
+    # the stream alone at this GPU's fill rate -- both below the launch as it is, neither negligible
+    assert 0.5 * r["avg_kernel_us"] < lim["kernel_us_without_sample_stores"] < r["avg_kernel_us"]
+    assert 0.4 * r["avg_kernel_us"] < lim["stream_alone_us_at_fill_rate"] < r["avg_kernel_us"]
 
 
 def test_strong_scaling_line():
