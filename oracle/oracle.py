@@ -316,6 +316,8 @@ class RefLoop:
         self.lib.refl2_run_mc.restype = C.c_double
         self.lib.refl2_run_gmm.restype = C.c_double
         self.lib.refl2_last_text.restype = C.c_longlong
+        self.lib.refl2_last_error.restype = C.c_longlong
+        self.lib.refl2_last_error.restype = C.c_longlong
         self.orc, self.pocs, self.plan, self.env = orc, pocs, plan, env
 
     def configure(self, particles, gaussians, samples):
@@ -351,6 +353,8 @@ class RefLoop:
         mu, cov = np.zeros(3), np.zeros(9)
         means, covs, checked = np.zeros((self.K, 3)), np.zeros((self.K, 9)), C.c_longlong(0)
         p = self.lib.refl2_run_gmm(C.c_uint(seed), C.c_uint(gen_seed), _p(mu), _p(cov), _p(means), _p(covs), C.byref(checked))
+        if p != p:                                   # the reference's run ended in an exception (it has no handling of its own)
+            return dict(p=p, error=self.last_error(), checked=checked.value)
         text = self.last_text()
         out = dict(p=p, mu=mu, cov=cov, means=means, covs=covs, checked=checked.value, probs=self.printed_probabilities(text),
                    counts=self.printed_counts(text))
@@ -361,6 +365,13 @@ class RefLoop:
                                       cnt.ctypes.data_as(C.POINTER(C.c_longlong)), _p(gmm), _p(chain))
             out.update(gmm=gmm, chain=chain)
         return out
+
+    def last_error(self):
+        """what() of the exception that ended the last run ("" if none): the reference has no handling of its own."""
+        n = self.lib.refl2_last_error(None, C.c_longlong(0))
+        buf = C.create_string_buffer(n + 1)
+        self.lib.refl2_last_error(buf, C.c_longlong(n + 1))
+        return buf.value.decode("ascii", "replace")
 
     def last_text(self):
         n = self.lib.refl2_last_text(None, C.c_longlong(0))

@@ -60,6 +60,7 @@ struct RefLoop {
 namespace {
 RefLoop* g = nullptr;
 std::string g_text;               // what the last run printed
+std::string g_error;              // what() of the exception that ended the last run, if one did
 struct Quiet {                    // the loop prints whole matrices through std::cout
   std::streambuf* old;
   std::ostringstream sink;
@@ -104,9 +105,12 @@ void refl2_configure(const double* alphas4, double Q, const double* lx, const do
 // particles (3 x N column-major = x y theta triples) and their collision counts.  Returns the proportion.
 double refl2_run_mc(unsigned seed, double* mu, double* cov, double* particles, unsigned* hits, long long* checked) {
   Quiet q;
+  g_error.clear();
   arma::arma_rng::set_seed(seed);
   g->checked = 0;
-  const double p = g->runSimulation();
+  double p;
+  try { p = g->runSimulation(); }
+  catch (const std::exception& e) { g_error = e.what(); return std::nan(""); }   // Armadillo throws (std::logic_error / runtime_error)
   for (int i = 0; i < 3; ++i) mu[i] = g->mu(i, 0);
   for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) cov[3 * r + c] = g->cov(r, c);
   for (size_t i = 0; i < (size_t)g->mcparticles.n_elem; ++i) particles[i] = g->mcparticles.memptr()[i];
@@ -128,10 +132,14 @@ void refl2_record_mc(unsigned seed, int N, int W, int L, double* init, double* c
 // last truncation (K means, K row-major covariances; the weights are private to GM_Model and stay so).
 double refl2_run_gmm(unsigned seed, unsigned gen_seed, double* mu, double* cov, double* means, double* covs, long long* checked) {
   Quiet q;
+  g_error.clear();
   arma::arma_rng::set_seed(seed);
   g->gmm.generator.seed(gen_seed);
   g->checked = 0;
-  const double p = g->runGMMEstimation();
+  double p;
+  try { p = g->runGMMEstimation(); }
+  catch (const std::exception& e) { g_error = e.what(); return std::nan(""); }   // e.g. mvnrnd on a covariance that is not positive
+                                                                                  // semi-definite, mean() of no samples: the reference dies there
   for (int i = 0; i < 3; ++i) mu[i] = g->mu(i, 0);
   for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) cov[3 * r + c] = g->cov(r, c);
   for (int k = 0; k < g->numGaussians; ++k) {
@@ -157,6 +165,13 @@ void refl2_record_gmm(unsigned seed, int N, int W, int L, int K, const long long
     }
     if (w < W - 1) for (int k = 0; k < 3 + L; ++k) chain[(size_t)w * (3 + L) + k] = randn();
   }
+}
+
+// what() of the exception that ended the last run (NaN returned), or "".
+long long refl2_last_error(char* buf, long long cap) {
+  const long long n = (long long)g_error.size();
+  if (buf && cap > 0) { const long long m = n < cap - 1 ? n : cap - 1; memcpy(buf, g_error.data(), (size_t)m); buf[m] = 0; }
+  return n;
 }
 
 // The text the last run printed (the reference reports the per-waypoint probabilities only there, :845-846).

@@ -133,3 +133,51 @@ def test_gmm_runs_with_three_gaussians_agree_in_law(ref, orc):
     se = np.sqrt(a.var(ddof=1) / runs + b.var(ddof=1) / runs)
     assert abs(a.mean() - b.mean()) < 4 * se, (a.mean(), b.mean(), se)
     assert stats.ks_2samp(a, b).pvalue > 1e-3, (np.sort(a), np.sort(b))
+
+
+def test_loop_on_the_second_scene_with_a_small_footprint(orc, pocs, plan):
+    """The same replay on the reference's other scene (pr2custom.env.xml: 29 boxes, 25 of them turned) with a
+    footprint small enough to pass between them, two Gaussians, the first 21 waypoints: runGMMEstimation() and
+    runSimulation() of the compiled loop against the oracle on the run's own noise."""
+    import oracle
+    from pathlib import Path as P
+    env = pocs.load_env(P(__file__).resolve().parent / "golden" / "pr2custom_env.txt")
+    env = dict(env, footprint=[0.0, 0.0, 0.12, 0.10])
+    sub = dict(traj=plan["traj"][:21], odom=plan["odom"][:20])
+    ref = oracle.RefLoop(orc, pocs, sub, env)
+    N = 2500
+    cfg = ref.configure(particles=200, gaussians=2, samples=N)
+    r = ref.run_gmm(41, gen_seed=9, record=True)
+    assert "error" not in r, r
+    orc.set_tapes(chain=r["chain"], gmm=r["gmm"], counts=r["counts"])
+    o = orc.run_gmm(cfg, 0, N)
+    assert abs(o["prob"] - r["p"]) < 1e-12 and np.allclose(o["probs"], r["probs"], rtol=0, atol=5.1e-5)
+    assert 0.0 < r["p"] < 1.0 and r["checked"] == N * 21
+    m = ref.run_mc(42)
+    orc.set_tapes(chain=m["chain"], init=m["init"])
+    n, hits, parts = orc.run_mc(cfg, 0, 200, want_particles=True)
+    assert np.array_equal(hits, m["hits"]) and n / 200 == m["p"] and 0 < n < 200
+    assert np.allclose(parts[:, :2], m["particles"][:, :2], rtol=0, atol=1e-9)
+
+
+def test_where_the_reference_has_no_defined_behaviour(orc, pocs, plan):
+    """Recorded, not matched.  On the second scene the plan runs into the furniture from waypoint ~25 on: every
+    sample of a Gaussian then collides, `noncollpoints` is empty, `mean` / `cov` of it are empty matrices
+    (MCSimulator.h:592-598), and the next EKFpredict indexes into them: the reference's own loop ends in an Armadillo
+    exception ("index out of bounds" / "incompatible matrix dimensions") -- inside OpenRAVE that is the end of the
+    module.  This build defines the case (degenerate cases): a component with fewer than two survivors is
+    retired with weight 0, and the estimation goes on; the oracle (and the HIP path, bit for bit) return a
+    probability."""
+    import oracle
+    from pathlib import Path as P
+    env = pocs.load_env(P(__file__).resolve().parent / "golden" / "pr2custom_env.txt")
+    env = dict(env, footprint=[0.0, 0.0, 0.12, 0.10])
+    sub = dict(traj=plan["traj"][:30], odom=plan["odom"][:29])
+    ref = oracle.RefLoop(orc, pocs, sub, env)
+    cfg = ref.configure(particles=10, gaussians=2, samples=2500)
+    r = ref.run_gmm(41, gen_seed=9)
+    assert r["p"] != r["p"] and ("out of bounds" in r["error"] or "incompatible" in r["error"]), r
+    orc.set_tapes()
+    o = orc.run_gmm(cfg, 41, 2500)
+    assert 0.0 < o["prob"] <= 1.0
+    assert np.any(o["states"][-1][:, 13] == 0.0)                 # a retired component is what kept it going
