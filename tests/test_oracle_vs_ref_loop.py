@@ -97,9 +97,8 @@ def test_gmm_run_with_three_gaussians_on_the_reference_tape(ref, orc):
     end to end against the reference's loop: per-component truncation, the weights from the survivor counts, the
     per-component EKF, the samples of a component as one block.  Per-waypoint probabilities as printed (four
     decimals), the final probability, the three Gaussians after the last truncation."""
-    N = 3000
-    cfg = ref.configure(particles=10, gaussians=3, samples=N)
-    for seed, gen_seed in ((31, 5), (32, 6), (33, 7)):
+    for N, seed, gen_seed in ((3000, 31, 5), (3000, 32, 6), (3000, 33, 7), (1000, 34, 8), (1000, 35, 9)):   # 1000: BASELINE configs[0]
+        cfg = ref.configure(particles=10, gaussians=3, samples=N)
         r = ref.run_gmm(seed, gen_seed=gen_seed, record=True)
         assert r["checked"] == N * ref.W and r["counts"].shape == (ref.W, 3)
         assert r["counts"][0].min() > N / 4 and r["counts"][-1].min() >= 0             # equal weights at the start
