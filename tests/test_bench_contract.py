@@ -139,3 +139,22 @@ def test_unequal_shares_of_the_two_blocks_of_a_cu_change_no_bit():
         d = json.loads(out.stdout.splitlines()[-1])
         base = base or d["config"]["probability"]
         assert d["config"]["probability"] == base and 0.0 < base < 1.0, (skew, d["config"]["probability"], base)
+
+
+def test_two_ranks_through_the_collective_path():
+    """The same two ranks with POCS_ONEHOP=0: one all-reduce per waypoint from Python (gloo here, RCCL on a node) --
+    the fallback bench.py takes when the one-hop probe fails.  Its launches and its collectives must be ordered on the
+    engine's stream (they were not when an engine had no stream of its own): the probability is
+    what one process gets for the whole mixture."""
+    import os
+    d = None
+    for onehop in ("0",):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        d = run_bench("--gpus", "2", "--no-cpu-baseline", "--steps", "2", "--warmup", "1",
+                      env=dict(env, POCS_FORCE_DEVICE="0", POCS_DIST_BACKEND="gloo", POCS_SKIP_SINGLE="1",
+                               POCS_NO_BOARD_PROBE="1", POCS_ONEHOP=onehop))
+        assert d["n_gpus"] == 2 and "all-reduce" in d["config"]["exchange"].lower() or "rccl" in d["config"]["exchange"].lower(), d["config"]["exchange"]
+    # two engines take the calls in turn: engine 0 ran one warm-up run and then the run whose probability the line
+    # carries -- its context's run 1, which is what one process reports after one warm-up run of one
+    one = run_bench("--no-cpu-baseline", "--samples", "40000", "--steps", "1", "--warmup", "1")
+    assert d["config"]["engines_in_flight"] == 2 and d["config"]["probability"] == one["config"]["probability"]
