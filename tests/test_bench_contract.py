@@ -158,3 +158,14 @@ def test_two_ranks_through_the_collective_path():
     # carries -- its context's run 1, which is what one process reports after one warm-up run of one
     one = run_bench("--no-cpu-baseline", "--samples", "40000", "--steps", "1", "--warmup", "1")
     assert d["config"]["engines_in_flight"] == 2 and d["config"]["probability"] == one["config"]["probability"]
+
+
+def test_two_ranks_mc_workload():
+    """--workload mc over two ranks (no data-path collective; one all-reduce of the hit counts): the proportion is
+    what one process reports for all the particles."""
+    import os
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = run_bench("--gpus", "2", "--workload", "mc", "--no-cpu-baseline", "--steps", "2", "--warmup", "2",
+                  env=dict(env, POCS_FORCE_DEVICE="0", POCS_DIST_BACKEND="gloo", POCS_SKIP_SINGLE="1", POCS_NO_BOARD_PROBE="1"))
+    one = run_bench("--workload", "mc", "--no-cpu-baseline", "--samples", "40000", "--steps", "2", "--warmup", "2")
+    assert d["n_gpus"] == 2 and "MC" in d["metric"] and d["config"]["probability"] == one["config"]["probability"]
