@@ -320,10 +320,11 @@ class RefLoop:
         self.lib.refl2_last_error.restype = C.c_longlong
         self.orc, self.pocs, self.plan, self.env = orc, pocs, plan, env
 
-    def configure(self, particles, gaussians, samples):
-        d = DEFAULTS if self.pocs is None else self.pocs.DEFAULTS
+    def configure(self, particles, gaussians, samples, params=None):
+        """params: dict(alphas, Q, landmarks 2 x L, cov0 3 x 3) in place of the reference's defaults."""
+        d = params or (DEFAULTS if self.pocs is None else self.pocs.DEFAULTS)
         lm = np.asarray(d["landmarks"], np.float64)
-        self.cfg = self.orc.config(self.plan, self.env, K=gaussians)
+        self.cfg = self.orc.config(self.plan, self.env, K=gaussians, alphas=d["alphas"], Q=d["Q"], landmarks=lm, cov0=d["cov0"])
         traj = np.ascontiguousarray(np.asarray(self.plan["traj"], np.float64).T)
         odom = np.ascontiguousarray(np.asarray(self.plan["odom"], np.float64).T)
         self.W, self.L, self.N, self.K = traj.shape[1], lm.shape[1], particles, gaussians

@@ -142,9 +142,10 @@ double refl2_run_gmm(unsigned seed, unsigned gen_seed, double* mu, double* cov, 
                                                                                   // semi-definite, mean() of no samples: the reference dies there
   for (int i = 0; i < 3; ++i) mu[i] = g->mu(i, 0);
   for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) cov[3 * r + c] = g->cov(r, c);
-  for (int k = 0; k < g->numGaussians; ++k) {
-    for (int i = 0; i < 3; ++i) means[3 * k + i] = g->gmm.means[k](i, 0);
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) covs[9 * k + 3 * r + c] = g->gmm.covariances[k](r, c);
+  for (int k = 0; k < g->numGaussians; ++k) {       // (a Gaussian whose last truncation left no sample holds EMPTY matrices: NaN)
+    const bool ok = g->gmm.means[k].n_elem == 3 && g->gmm.covariances[k].n_elem == 9;
+    for (int i = 0; i < 3; ++i) means[3 * k + i] = ok ? g->gmm.means[k](i, 0) : std::nan("");
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) covs[9 * k + 3 * r + c] = ok ? g->gmm.covariances[k](r, c) : std::nan("");
   }
   *checked = g->checked;
   return p;

@@ -180,3 +180,58 @@ def test_where_the_reference_has_no_defined_behaviour(orc, pocs, plan):
     o = orc.run_gmm(cfg, 41, 2500)
     assert 0.0 < o["prob"] <= 1.0
     assert np.any(o["states"][-1][:, 13] == 0.0)                 # a retired component is what kept it going
+
+
+def test_replay_on_random_problems(orc, pocs, plan):
+    """The replay as a fuzz: 60 random problems -- a stretch of the bundled plan (5 to 40 waypoints from a random
+    start), its own noise levels, sensor variance, landmark set (2 to 8), initial covariance, one to three Gaussians,
+    500 to 3000 samples, a random world of one to six boxes (a third of them turned) around the path and a random,
+    mostly off-centre footprint -- each run by the reference's compiled loop (GMM and MC) and replayed by the oracle on
+    the run's own noise.  Where the reference ends in an exception (a Gaussian without survivors, test above) the case
+    counts as skipped; everywhere else: final probability 1e-12, printed per-waypoint probabilities, every particle's
+    collision counter."""
+    import oracle
+    rng = np.random.default_rng(20260)
+    done = skipped = informative = 0
+    traj, odom = np.asarray(plan["traj"], np.float64), np.asarray(plan["odom"], np.float64)
+    for case in range(60):
+        W = int(rng.integers(5, 41))
+        s = int(rng.integers(0, len(traj) - W + 1))
+        sub = dict(traj=traj[s:s + W], odom=odom[s:s + W - 1])
+        L = int(rng.integers(2, 9))
+        params = dict(alphas=list(np.asarray(pocs.DEFAULTS["alphas"]) * 10.0 ** rng.uniform(-1, 1.5, 4)), Q=float(10.0 ** rng.uniform(-3, -0.5)),
+                      landmarks=np.vstack([rng.uniform(-5, 5, L), rng.uniform(-5, 5, L)]),
+                      cov0=np.diag(10.0 ** rng.uniform(-4, -2, 3)))
+        M = int(rng.integers(1, 7))
+        boxes = []
+        for _ in range(M):
+            i = int(rng.integers(0, W))
+            ang, dist = rng.uniform(0, 2 * np.pi), rng.uniform(0.45, 1.3)         # beside the path, not on it
+            off = dist * np.array([np.cos(ang), np.sin(ang)])
+            boxes.append([sub["traj"][i][0] + off[0], sub["traj"][i][1] + off[1], rng.uniform(0.03, 0.3), rng.uniform(0.03, 0.3),
+                          rng.choice([0.0, 0.0, rng.uniform(-3, 3)])])
+        env = dict(footprint=[rng.choice([0.0, rng.uniform(-0.1, 0.1)]), rng.choice([0.0, rng.uniform(-0.1, 0.1)]),
+                              rng.uniform(0.03, 0.18), rng.uniform(0.03, 0.18)], boxes=np.array(boxes))
+        K, N = int(rng.integers(1, 4)), int(rng.integers(500, 3001))
+        ref = oracle.RefLoop(orc, pocs, sub, env)
+        cfg = ref.configure(particles=150, gaussians=K, samples=N, params=params)
+        r = ref.run_gmm(1000 + case, gen_seed=77 + case, record=True)
+        if "error" in r:
+            skipped += 1
+            continue
+        orc.set_tapes(chain=r["chain"], gmm=r["gmm"], counts=r["counts"])
+        o = orc.run_gmm(cfg, 0, N)
+        if np.any(o["states"][:, :, 13] == 0.0):          # the oracle retired a component the reference limped on with (< 2 survivors)
+            skipped += 1
+            continue
+        assert abs(o["prob"] - r["p"]) < 1e-12, (case, o["prob"], r["p"])
+        assert np.allclose(o["probs"], r["probs"], rtol=0, atol=5.1e-5), case
+        m = ref.run_mc(2000 + case)
+        orc.set_tapes(chain=m["chain"], init=m["init"])
+        n, hits, _ = orc.run_mc(cfg, 0, 150, want_particles=True)
+        assert np.array_equal(hits, m["hits"]) and n / 150 == m["p"], case
+        orc.set_tapes()
+        done += 1
+        informative += 0.0 < r["p"] < 1.0
+    print('replayed', done, 'skipped', skipped, 'informative', informative)
+    assert done >= 30 and informative >= 12, (done, skipped, informative)
