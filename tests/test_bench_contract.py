@@ -169,3 +169,15 @@ def test_two_ranks_mc_workload():
                   env=dict(env, POCS_FORCE_DEVICE="0", POCS_DIST_BACKEND="gloo", POCS_SKIP_SINGLE="1", POCS_NO_BOARD_PROBE="1"))
     one = run_bench("--workload", "mc", "--no-cpu-baseline", "--samples", "40000", "--steps", "2", "--warmup", "2")
     assert d["n_gpus"] == 2 and "MC" in d["metric"] and d["config"]["probability"] == one["config"]["probability"]
+
+
+def test_two_ranks_strong_scaling():
+    """--scaling strong over two ranks: the workload's samples in total, half per rank -- the probability of the same
+    total in one process."""
+    import os
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = run_bench("--gpus", "2", "--scaling", "strong", "--no-cpu-baseline", "--steps", "4", "--warmup", "2",
+                  env=dict(env, POCS_FORCE_DEVICE="0", POCS_DIST_BACKEND="gloo", POCS_SKIP_SINGLE="1", POCS_NO_BOARD_PROBE="1"))
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_samples_per_run"] == 20000 and d["config"]["samples_per_gpu"] == 10000
+    one = run_bench("--no-cpu-baseline", "--steps", "4", "--warmup", "2")
+    assert d["config"]["probability"] == one["config"]["probability"]
