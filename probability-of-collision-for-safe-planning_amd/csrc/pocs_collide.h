@@ -34,34 +34,40 @@ POCS_HD void pocs_prepare_obstacle(const double box5[5], const pocs_footprint* f
 // in IEEE arithmetic (gradual underflow), so each pair of tests folds into one compare of the larger
 // margin.  An axis-aligned obstacle (axis exactly (1, 0)) takes a shorter path that produces the
 // same values: fma(c, 1, s*0) == c, fma(dx, 1, dy*0) == dx.
-POCS_HD bool pocs_box_narrow(double px, double py, double sn, double cs, double rx, double ry,
-                             const double* o) {
-  const double dx = o[0] - px;
-  const double dy = o[1] - py;
-  const double ax = o[2], ay = o[3], hx = o[4], hy = o[5];
-  double acr, asr, e1, e2;
-  if (ax == 1.0 && ay == 0.0) {                                   // wave-uniform
-    acr = fabs(cs); asr = fabs(sn); e1 = dx; e2 = dy;
-  } else {
-    acr = fabs(fma(cs, ax, sn * ay));                             // |cos| of the relative yaw
-    asr = fabs(fma(sn, ax, -(cs * ay)));                          // |sin| of the relative yaw
-    e1 = fma(dx, ax, dy * ay);                                    // d in the obstacle frame
-    e2 = fma(dy, ax, -(dx * ay));
-  }
+// The margins of the four axes given the relative yaw (cr, sr: cosine and sine, signed) and the offset in the
+// obstacle's frame (e1, e2).  Inlined into BOTH paths of pocs_box_narrow below instead of after their merge: merged,
+// the compiler materialises |cos|, |sin| and copies of the offsets into fresh registers for the common tail (six
+// vector moves per pose and record in the axis-aligned case); in place, the absolute values are operand modifiers.
+POCS_HD bool pocs_box_margins(double dx, double dy, double sn, double cs, double rx, double ry, double hx, double hy,
+                              double cr, double sr, double e1, double e2) {
   // The obstacle's own two axes first: they separate nearly every pose that is in reach but does not
   // touch (a wall and a robot driving past it), and a wave whose poses are all separated there skips
   // the footprint's axes.  (max of the four margins > 0  <=>  one of the two maxima > 0.)
-  const double m3 = fabs(e1) - (hx + fma(rx, acr, ry * asr));
-  const double m4 = fabs(e2) - (hy + fma(rx, asr, ry * acr));
+  const double m3 = fabs(e1) - (hx + fma(rx, fabs(cr), ry * fabs(sr)));
+  const double m4 = fabs(e2) - (hy + fma(rx, fabs(sr), ry * fabs(cr)));
   if (fmax(m3, m4) > 0.0) return false;
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("; footprint axes");                                // keeps the early return a branch
 #endif
   const double d1 = fma(dx, cs, dy * sn);                         // d in the footprint frame
   const double d2 = fma(dy, cs, -(dx * sn));
-  const double m1 = fabs(d1) - (rx + fma(hx, acr, hy * asr));
-  const double m2 = fabs(d2) - (ry + fma(hx, asr, hy * acr));
+  const double m1 = fabs(d1) - (rx + fma(hx, fabs(cr), hy * fabs(sr)));
+  const double m2 = fabs(d2) - (ry + fma(hx, fabs(sr), hy * fabs(cr)));
   return !(fmax(m1, m2) > 0.0);
+}
+
+POCS_HD bool pocs_box_narrow(double px, double py, double sn, double cs, double rx, double ry,
+                             const double* o) {
+  const double dx = o[0] - px;
+  const double dy = o[1] - py;
+  const double ax = o[2], ay = o[3], hx = o[4], hy = o[5];
+  if (ax == 1.0 && ay == 0.0)                                     // wave-uniform: the relative yaw IS the heading, the offset as it is
+    return pocs_box_margins(dx, dy, sn, cs, rx, ry, hx, hy, cs, sn, dx, dy);
+  return pocs_box_margins(dx, dy, sn, cs, rx, ry, hx, hy,
+                          fma(cs, ax, sn * ay),                   // cos of the relative yaw
+                          fma(sn, ax, -(cs * ay)),                // sin of the relative yaw
+                          fma(dx, ax, dy * ay),                   // d in the obstacle frame
+                          fma(dy, ax, -(dx * ay)));
 }
 
 // Broad phase + narrow phase against one record (host-side convenience, same result).
