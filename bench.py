@@ -14,11 +14,17 @@ samples (--scaling strong: BASELINE.json configs[3] = `--workload cfg3 --scaling
 per waypoint the moments of the whole batch (batch x 11 K doubles) are summed over ranks with ONE
 RCCL all-reduce.
 
+Timing: after the warm-up the K-step pass is repeated -- at least 10 times and for about a second
+of GPU time, each repeat bracketed by barrier + synchronize on both sides and taken as the MAX over ranks --
+and `ms_per_step` / `value` are the MEDIAN repeat's; min / max / repeats travel in `timing`.
+
 Prints ONE JSON line on rank 0 (fields: DESIGN.md section 7).
 """
 import argparse
 import json
+import math
 import os
+import statistics
 import sys
 import time
 from importlib import import_module
@@ -28,9 +34,12 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-NUMERICS = "v7"                 # counter records of another numerics version describe another kernel
+NUMERICS = "v8"                 # counter records of another numerics version describe another kernel
 BYTES_PER_EVAL_GMM = 26         # 3 x f64 sample + i16 flag streamed out once
 BYTES_PER_EVAL_MC = 56          # 24 B in + 24 B out + u32 hit counter read + write
+CPU_BUDGET_FACTOR = 3           # the CPU baseline may take this many times the wall time of the run's GPU part
+TIMED_TARGET_S = float(os.environ.get("POCS_BENCH_TARGET_S", "1.0"))   # GPU time the repeats of the timed pass add up to
+MC_CACHE_BYTES = 232.0e6        # particle state of a batch up to this size stays in the 256 MB Infinity Cache (pocs_host.hip)
 
 WORKLOADS = {
     # name: (waypoints, samples per GPU, components, path)
@@ -41,25 +50,34 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(plan, env, K, W, path, budget_evals):
-    """The oracle (single-thread C restatement, like the reference, which has no threading) timed on
-    this host on a bounded sample; beside it the same restatement on every core the process may
-    use, one independent run per thread (the reference's 200 runs are independent)."""
+def cpu_baseline(plan, env, K, W, path, budget_evals, budget_s=None):
+    """The reference's own loop (compiled from MCSimulator.h into oracle/_ref where that travelled with the tree) and
+    the oracle (single-thread C restatement) timed on this host on a bounded sample: 1 thread (the reference has no
+    threading), then the restatement on one GPU's share of the host (16 threads) and on EVERY core the process may use,
+    one independent run per thread (the reference's 200 runs are independent).  budget_s: wall seconds the whole
+    baseline may take -- the caller passes a stated multiple of what the GPU part took, so that the GPU part is not a
+    blip in the run; the sample is sized from a short calibration run."""
     import threading
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle
     orc = oracle.Oracle()
     cfg = orc.config(plan, env, K=K)
-    n = max(1000, int(budget_evals // W))
 
-    def one(seed):
+    def one(seed, n):
         if path == "gmm":
             orc.run_gmm(cfg, seed, n)
         else:
             orc.run_mc(cfg, seed, n)
 
+    n = max(1000, int(budget_evals // W))
+    legs = 4 if oracle.RefLoop.LIB.exists() else 3
+    if budget_s is not None:
+        t0 = time.perf_counter()
+        one(99, 2000)
+        rate = 2000 * W / (time.perf_counter() - t0)           # evaluations per second of one thread, roughly
+        n = max(1000, min(n, int(0.8 * rate * budget_s / legs / W)))
     t0 = time.perf_counter()
-    one(1234)
+    one(1234, n)
     dt = time.perf_counter() - t0
     out = {"value": n * W / dt, "unit": "particle-waypoint evals/s", "cores": 1, "kind": "port",
            "sample": "%d samples x %d waypoints (%s path, K=%d), oracle/pocs_oracle.c, 1 thread, %.1f s"
@@ -77,6 +95,9 @@ def cpu_baseline(plan, env, K, W, path, budget_evals):
     except OSError:
         pass
     out["nproc"], out["cpu_model"] = ncpu, model
+    if budget_s is not None:
+        out["budget"] = "the whole baseline sized to <= %.1f s = %s x the %.1f s the GPU part of this run took" % (
+            budget_s, CPU_BUDGET_FACTOR, budget_s / CPU_BUDGET_FACTOR)
     # the reference's OWN loop where its compiled pieces travelled with the tree (oracle/_ref, built by `make -C oracle
     # ref_loop` from MCSimulator.h where it lies; nothing of /root/reference is read here): runGMMEstimation() /
     # runSimulation() on the same plan, world and sample.  It then IS the baseline ("kind": "reference") and the
@@ -88,30 +109,43 @@ def cpu_baseline(plan, env, K, W, path, budget_evals):
             ref.configure(particles=n if path == "mc" else 10, gaussians=K, samples=n if path == "gmm" else 10)
             t0 = time.perf_counter()
             if path == "gmm":
-                ref.run_gmm(4321, gen_seed=8765)
+                res = ref.run_gmm(4321, gen_seed=8765)
+                p_ref, err = res["p"], res.get("error")
             else:
-                ref.time_mc(4321)
+                p_ref, err = ref.time_mc(4321), None
             dtr = time.perf_counter() - t0
-            port = {k: out[k] for k in ("value", "cores", "kind", "sample")}
-            out.update({"value": n * W / dtr, "cores": 1, "kind": "reference", "port": port,
-                        "sample": "%d samples x %d waypoints (%s path, K=%d): the reference's own %s compiled from "
-                                  "MCSimulator.h (oracle/_ref/libpocs_ref_loop.so), its one OpenRAVE collision call "
-                                  "replaced by this build's 2-D predicate, 1 thread, %.1f s"
-                                  % (n, W, path, K, "runGMMEstimation()" if path == "gmm" else "runSimulation()", dtr)})
+            # the reference has no error handling of its own: a run that threw (a Gaussian that lost all its samples)
+            # ended EARLY and returns NaN -- its time is not the time of a run, and the restatement's figure stands
+            if err or p_ref != p_ref:
+                out["reference_error"] = ("the reference's loop threw: %s" % (err or ref.last_error()))[:200]
+            else:
+                port = {k: out[k] for k in ("value", "cores", "kind", "sample")}
+                out.update({"value": n * W / dtr, "cores": 1, "kind": "reference", "port": port, "reference_probability": p_ref,
+                            "sample": "%d samples x %d waypoints (%s path, K=%d): the reference's own %s compiled from "
+                                      "MCSimulator.h (oracle/_ref/libpocs_ref_loop.so), its one OpenRAVE collision call "
+                                      "replaced by this build's 2-D predicate, 1 thread, %.1f s"
+                                      % (n, W, path, K, "runGMMEstimation()" if path == "gmm" else "runSimulation()", dtr)})
         except Exception as e:                                                    # noqa: BLE001 -- the port stands
             out["reference_error"] = repr(e)[:200]
-    ncpu = min(ncpu, int(os.environ.get("POCS_CPU_THREADS", "16")))      # one GPU's share of the host on the pool
-    if ncpu > 1:
-        th = [threading.Thread(target=one, args=(2000 + i,)) for i in range(ncpu)]      # ctypes releases the GIL
+
+    def threaded(nthreads, n_each):
+        th = [threading.Thread(target=one, args=(2000 + i, n_each)) for i in range(nthreads)]      # ctypes releases the GIL
         t0 = time.perf_counter()
         for t in th:
             t.start()
         for t in th:
             t.join()
         dta = time.perf_counter() - t0
-        out["all_cores"] = {"value": ncpu * n * W / dta, "cores": ncpu,
-                            "kind": "port",
-                            "sample": "%d independent runs of the restatement's sample, one per thread, %.1f s" % (ncpu, dta)}
+        return {"value": nthreads * n_each * W / dta, "cores": nthreads, "kind": "port",
+                "sample": "%d independent runs of %d samples of the restatement, one per thread, %.1f s" % (nthreads, n_each, dta)}
+
+    share = min(ncpu, int(os.environ.get("POCS_CPU_THREADS", "16")))      # one GPU's share of the host on the pool
+    if share > 1:
+        out["all_cores"] = threaded(share, n)
+        out["all_cores"]["note"] = "one GPU's share of this host (POCS_CPU_THREADS, default 16)"
+    if ncpu > share:                                                      # ... and the whole host: every core the process may use
+        out["host_cores"] = threaded(ncpu, max(1000, n // 2))
+        out["host_cores"]["note"] = "every core of the host this process may run on (sched_getaffinity)"
     return out
 
 
@@ -254,21 +288,56 @@ def spawn_ranks(n):
                   "(rehearse the multi-rank path on one card with POCS_FORCE_DEVICE=0 POCS_DIST_BACKEND=gloo)" % (n, have, n),
                   file=sys.stderr)
             return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for rank in range(n):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        # rank 0 inherits stdout (the one JSON line); the other ranks must print nothing there
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if rank == 0 else subprocess.DEVNULL))
-    rcs = [p.wait() for p in procs]
-    if any(rcs):
-        print("bench.py: ranks exited with %s" % rcs, file=sys.stderr)
-        return 1
-    return 0
+    for attempt in range(3):                              # the port is free when probed; another process may take it before
+        with socket.socket() as sk:                       # rank 0 listens: a rendezvous that fails that way is tried again
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for rank in range(n):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            # rank 0's stdout (the one JSON line) is held back until every rank has succeeded; the others print nothing there
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL,
+                                          stderr=subprocess.PIPE if rank == 0 else None, text=True))
+        # poll: the first rank to fail ends the job at once -- the others would sit in their collectives until the device
+        # wait (30 s) or the process group's timeout (minutes) otherwise
+        import threading
+        grabbed = {}
+        t_out = threading.Thread(target=lambda: grabbed.update(out=procs[0].stdout.read()), daemon=True)
+        t_err = threading.Thread(target=lambda: grabbed.update(err=procs[0].stderr.read()), daemon=True)
+        t_out.start(); t_err.start()
+        failed = None
+        while failed is None and any(p.poll() is None for p in procs):
+            for i, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = i
+                    break
+            time.sleep(0.05)
+        if failed is None:
+            failed = next((i for i, p in enumerate(procs) if p.returncode != 0), None)
+        if failed is not None:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        t_out.join(timeout=10); t_err.join(timeout=10)
+        err = grabbed.get("err", "") or ""
+        if failed is not None and attempt < 2 and ("EADDRINUSE" in err or "Address already in use" in err or "address already in use" in err):
+            print("bench.py: rendezvous port %d was taken before rank 0 listened; trying another" % port, file=sys.stderr)
+            continue
+        sys.stderr.write(err)
+        if failed is not None:
+            print("bench.py: rank %d exited with %s; the other ranks were stopped (%s)" % (failed, procs[failed].returncode, [p.returncode for p in procs]), file=sys.stderr)
+            return 1
+        sys.stdout.write(grabbed.get("out", "") or "")
+        sys.stdout.flush()
+        return 0
+    return 1
 
 
 def main():
@@ -289,7 +358,10 @@ def main():
     ap.add_argument("--mc-fused", action="store_true",
                     help="MC workloads: whole roll-out in registers (k_mc_fused, ~0 B/eval) instead of streaming")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-evals", type=float, default=6.0e7, help="size of the CPU baseline sample")
+    ap.add_argument("--no-strong-record", action="store_true",
+                    help="N > 1: skip the short strong-scaling pass (cfg3 split over the ranks = BASELINE configs[3] at N = 8) "
+                         "that the default weak line carries as `strong`")
+    ap.add_argument("--cpu-evals", type=float, default=6.0e7, help="upper bound of the CPU baseline's sample (evaluations)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))          # this process never touches the GPU: it starts the ranks and relays
@@ -299,6 +371,7 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    t_process = time.perf_counter()
 
     import torch
     import pocs_amd
@@ -321,108 +394,24 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # RCCL over xGMI
         else:
             dist.init_process_group(backend)
-
-    W, n_local, K, path = WORKLOADS[args.workload]
-    if args.samples:
-        n_local = args.samples
-    if args.scaling == "strong":           # the same total workload over more GPUs (even shards: pairs of samples share draws)
-        n_local = max(2, (n_local // world) & ~1)
-    plan = pocs_amd.load_plan()
-    if W != 56:
-        plan = pocs_amd.resample_plan(plan, W)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     env = pocs_amd.load_env()
-    N = n_local * world
 
-    # K steps are issued as `ncalls` calls of nearly equal batch: `n_hi` calls of b_hi = b_lo + 1
-    # runs and the rest of b_lo runs.
-    # MC: as many roll-outs per launch as keep 8 x 10^6 particles' state (28 B each) in flight -- what stays in
-    # the 256 MB Infinity Cache between two waypoint launches: 8 at 10^6 particles, 64 at 10^5 (cfg5: 0.41 -> 0.75)
-    maxb = args.batch if args.batch > 0 else (64 if path == "gmm" else max(1, min(64, int(8_000_000 // max(n_local, 1)))))
-    ncalls = (args.steps + maxb - 1) // maxb
-    # How the shards of the GMM path exchange their moments (POCS_ONEHOP): "2" = the library's one-hop
-    # exchange in the sampling launch's tail (one launch per waypoint, ONE engine, as on one GPU; the
-    # default for N > 1, after a small end-to-end probe of it on this node has succeeded on every rank),
-    # "1" = the one-hop exchange as its own launch, "0" = one RCCL all-reduce per waypoint (two engines).
-    xmode = os.environ.get("POCS_ONEHOP", "2" if (sharded and WORKLOADS[args.workload][3] == "gmm") else "0")
-    xnote = None
-    if sharded and xmode == "2" and "POCS_ONEHOP" not in os.environ:
-        ok = probe_onehop(par, pocs_amd, torch, dist if world > 1 else None, rank, world, local)
-        if not ok:
-            xmode, xnote = "0", "one-hop probe failed on this node: fell back to RCCL"
-    os.environ["POCS_ONEHOP"] = xmode
-    fused_exchange = xmode == "2"
-    if sharded and path == "gmm" and args.steps >= 2 and not fused_exchange:
-        # N > 1: an even number of calls, so that two engines are always in flight and one engine's
-        # all-reduce is covered by the other's kernel
-        ncalls = max(2, ncalls + (ncalls & 1))
-        ncalls = min(ncalls, args.steps - (args.steps & 1)) or 2
-    b_lo, n_hi = divmod(args.steps, ncalls)
-    b_hi = b_lo + 1 if n_hi else b_lo
-    batch = b_hi
-    chunks = [b_hi] * (n_hi if n_hi else ncalls) + ([b_lo] * (ncalls - n_hi) if n_hi else [])
+    def over_ranks(values, op):
+        """all_reduce of a few doubles (MAX / MIN / SUM); the identity on one rank."""
+        if dist is None:
+            return list(values)
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=op)
+        return t.tolist()
 
-    def make(b, seed, stream=None):
-        c = pocs_amd.Context(local)
-        c.configure(plan, env, K=K, N=N, seed=seed)
-        if args.mc_fused:
-            c.set_option(pocs_amd.OPT_MC_FUSED, 1)
-        if os.environ.get("POCS_NO_STORE") == "1":       # tuning only: samples not written to HBM
-            c.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
-        if os.environ.get("POCS_NO_GRAPH") == "1":       # diagnostic builds that synchronise inside the launch sequence
-            c.set_option(pocs_amd.OPT_USE_GRAPH, 0)
-        if sharded:     # one rank per GPU: launches on a torch stream, moments in a torch tensor
-            return c, par.GpuEngine(c, W, K, N, rank=rank, world=world, per_rank=n_local, batch=b, stream=stream)
-        c.set_batch(b)
-        c.set_shard(0, n_local)
-        return c, None
-
-    if not sharded:
-        # one GPU: each distinct batch size has its own context (and its own captured hipGraph)
-        made = [make(b_hi, 0x5EED0001)]
-        if b_lo != b_hi and b_lo in chunks:
-            made.append(make(b_lo, 0x5EED0002))
-        ctx = made[0][0]
-        engines = []
-
-        def run_steps(sizes):
-            p = 0.0
-            for b in sizes:
-                c = made[0][0] if b == b_hi else made[1][0]
-                p = c.run_gmm_estimation() if path == "gmm" else c.run_simulation()
-            return p
-    else:
-        # one rank per GPU: two engines on two streams take the calls in turn, so one engine's
-        # kernel runs while the other's moments are in the all-reduce (parallel.run_gmm_pipelined)
-        n_eng = 2 if (path == "gmm" and len(chunks) >= 2 and not fused_exchange) else 1
-        if fused_exchange and path == "gmm" and len(chunks) >= 2 and os.environ.get("POCS_ENGINES") == "2":
-            # skew tolerance: a second batch of runs in flight on a stream of its own -- while one
-            # engine's closers wait for the slowest rank's moments, the other engine's sampling blocks have the chip
-            n_eng = 2
-        # (every engine on a torch stream of its own: its launches, its collectives and its event waits in one order)
-        made = [make(b_hi, 0x5EED0001 + i, torch.cuda.Stream()) for i in range(n_eng)]
-        ctx = made[0][0]
-        engines = [e for _, e in made]
-        # POCS_ONEHOP=1: the library's own exchange (IPC-mapped slots, one hop over xGMI, sum + mixture
-        # advance in one small launch) instead of one RCCL all-reduce per waypoint from Python
-        onehop = path == "gmm" and xmode in ("1", "2")
-        run_onehop = par.run_gmm_onehop_fused if xmode == "2" else par.run_gmm_onehop
-        if onehop:
-            for e in engines:
-                e.connect_onehop(dist if world > 1 else None, rank, world)
-
-        def run_steps(sizes):
-            p = 0.0
-            if path != "gmm":
-                for _ in sizes:
-                    p = par.run_mc_sharded(engines[0], N, dist)      # one all_reduce of the hit count
-                return p
-            for i in range(0, len(sizes), n_eng):
-                group = sizes[i:i + n_eng]
-                for e, b in zip(engines, group):
-                    if e.batch != b:
-                        e.set_batch(b)
-                p = (run_onehop(engines[:len(group)]) if onehop else par.run_gmm_pipelined(engines[:len(group)], dist))[0]
-            return p
+    def gather_ranks(value):
+        if dist is None:
+            return [float(value)]
+        t = torch.zeros(world, dtype=torch.float64, device=coll_dev)
+        t[rank] = float(value)
+        dist.all_reduce(t)
+        return t.tolist()
 
     def fence():
         torch.cuda.synchronize()
@@ -430,92 +419,294 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    warm = [b_hi] * max(1, (args.warmup + batch - 1) // batch) + ([b_lo] if b_lo != b_hi else [])          # >= W untimed steps
-    if sharded and path == "gmm" and xmode in ("1", "2"):
-        # the one-hop exchange has passed a small probe; the warm-up is its first run at full size.  Should it fail
-        # there on any rank (the kernel's bounded wait gives up after 30 s and the call returns POCS_E_DEVICE), every
-        # rank switches to the RCCL path for the timed region -- agreed by a collective, so that nobody is left behind.
-        ok = 1.0
-        try:
-            run_steps(warm)
-        except pocs_amd.PocsError as exc:
-            print("rank %d: one-hop exchange failed in the warm-up: %s" % (rank, exc), file=sys.stderr)
-            ok = 0.0
-        if dist is not None:
-            t = torch.tensor([ok], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = t.item()
+    # How the shards of the GMM path exchange their moments (POCS_ONEHOP): "2" = the library's one-hop
+    # exchange in the sampling launch's tail (one launch per waypoint, ONE engine, as on one GPU; the
+    # default for N > 1, after a small end-to-end probe of it on this node has succeeded on every rank),
+    # "1" = the one-hop exchange as its own launch, "0" = one RCCL all-reduce per waypoint (two engines).
+    xstate = {"mode": os.environ.get("POCS_ONEHOP", "2" if (sharded and WORKLOADS[args.workload][3] == "gmm") else "0"),
+              "note": None, "probe": None}
+    if sharded and xstate["mode"] == "2" and "POCS_ONEHOP" not in os.environ:
+        t0 = time.perf_counter()
+        ok = probe_onehop(par, pocs_amd, torch, dist if world > 1 else None, rank, world, local)
+        xstate["probe"] = {"ok": bool(ok), "seconds": time.perf_counter() - t0,
+                           "what": "one small sharded GMM call through the library's IPC exchange on this node, every rank, before anything is timed"}
         if not ok:
-            xmode, xnote, onehop = "0", "one-hop exchange failed in the warm-up at full size: fell back to RCCL", False
-            run_steps(warm)
-    else:
-        run_steps(warm)
-    fence()
-    t0 = time.perf_counter()
-    prob = run_steps(chunks)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    evals = float(N) * W * args.steps
-    value = evals / dt
+            xstate["mode"], xstate["note"] = "0", "one-hop probe failed on this node: fell back to RCCL"
+    os.environ["POCS_ONEHOP"] = xstate["mode"]
 
-    # roofline of the dominant kernel: further calls with the hot kernel bracketed by hipEvents on
-    # the launch stream (eager launches; not part of `value`)
-    ctx.set_option(pocs_amd.OPT_PROFILE, 1)
-    ms_tot, n_launch, groups, waypoint_us = 0.0, 0, 1, None
-    for _ in range(max(1, min(len(chunks), 3))):
-        if engines:
-            if engines[0].batch != b_hi:
-                engines[0].set_batch(b_hi)
-            if path == "gmm":
-                (run_onehop(engines[:1]) if onehop else par.run_gmm_pipelined(engines[:1], dist))
-            else:
-                par.run_mc_sharded(engines[0], N, dist)
+    def measure(workload, scaling, steps, warmup, batch_arg, samples, full):
+        """One workload through the timing protocol; full = the main record (roofline extras, single call, board)."""
+        W, n_local, K, path = WORKLOADS[workload]
+        if samples:
+            n_local = samples
+        if scaling == "strong":           # the same total workload over more GPUs (even shards: pairs of samples share draws)
+            n_local = max(2, (n_local // world) & ~1)
+        plan = pocs_amd.load_plan()
+        if W != 56:
+            plan = pocs_amd.resample_plan(plan, W)
+        N = n_local * world
+        xmode = xstate["mode"] if path == "gmm" else "0"
+
+        # K steps are issued as `ncalls` calls of nearly equal batch: `n_hi` calls of b_hi = b_lo + 1
+        # runs and the rest of b_lo runs.
+        # MC: as many roll-outs per launch as keep 8 x 10^6 particles' state (28 B each) in flight -- what stays in
+        # the 256 MB Infinity Cache between two waypoint launches: 8 at 10^6 particles, 64 at 10^5 (cfg5: 0.41 -> 0.75)
+        maxb = batch_arg if batch_arg > 0 else (64 if path == "gmm" else max(1, min(64, int(8_000_000 // max(n_local, 1)))))
+        ncalls = (steps + maxb - 1) // maxb
+        fused_exchange = xmode == "2"
+        if sharded and path == "gmm" and steps >= 2 and not fused_exchange:
+            # N > 1: an even number of calls, so that two engines are always in flight and one engine's
+            # all-reduce is covered by the other's kernel
+            ncalls = max(2, ncalls + (ncalls & 1))
+            ncalls = min(ncalls, steps - (steps & 1)) or 2
+        b_lo, n_hi = divmod(steps, ncalls)
+        b_hi = b_lo + 1 if n_hi else b_lo
+        batch = b_hi
+        chunks = [b_hi] * (n_hi if n_hi else ncalls) + ([b_lo] * (ncalls - n_hi) if n_hi else [])
+
+        def make(b, seed, stream=None):
+            c = pocs_amd.Context(local)
+            c.configure(plan, env, K=K, N=N, seed=seed)
+            if args.mc_fused:
+                c.set_option(pocs_amd.OPT_MC_FUSED, 1)
+            if os.environ.get("POCS_NO_STORE") == "1":       # tuning only: samples not written to HBM
+                c.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
+            if os.environ.get("POCS_NO_GRAPH") == "1":       # diagnostic builds that synchronise inside the launch sequence
+                c.set_option(pocs_amd.OPT_USE_GRAPH, 0)
+            if sharded:     # one rank per GPU: launches on a torch stream, moments in a torch tensor
+                return c, par.GpuEngine(c, W, K, N, rank=rank, world=world, per_rank=n_local, batch=b, stream=stream)
+            c.set_batch(b)
+            c.set_shard(0, n_local)
+            return c, None
+
+        onehop, run_onehop = False, None
+        if not sharded:
+            # one GPU: each distinct batch size has its own context (and its own captured hipGraph)
+            made = [make(b_hi, 0x5EED0001)]
+            if b_lo != b_hi and b_lo in chunks:
+                made.append(make(b_lo, 0x5EED0002))
+            ctx = made[0][0]
+            engines = []
+
+            def run_steps(sizes):
+                p = 0.0
+                for b in sizes:
+                    c = made[0][0] if b == b_hi else made[1][0]
+                    p = c.run_gmm_estimation() if path == "gmm" else c.run_simulation()
+                return p
         else:
-            run_steps([b_hi])
-        ms, n = ctx.kernel_time()
-        ms_tot += ms
-        n_launch += n
-        if path == "gmm" and not engines and hasattr(ctx.lib, "pocs_get_sequence_time"):      # (an A/B library of an older commit has none)
-            seq_ms, groups = ctx.sequence_time()
-            waypoint_us = seq_ms * 1e3 / W
-    # the same launches WITHOUT the sample stores (POCS_OPT_STORE_SAMPLES = 0: a product option, same arithmetic, same
-    # results): what the arithmetic alone takes on this box, to set beside what the stream alone would take at the fill
-    # rate -- the two meet at the board's power cap; not part of `value`
-    nostore_ms = None
-    if path == "gmm" and not engines and os.environ.get("POCS_NO_STORE") != "1":
-        ctx.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
-        run_steps([b_hi])                            # (the graph / buffers of this variant)
-        t_ms, t_n = 0.0, 0
-        for _ in range(max(1, min(len(chunks), 2))):
-            run_steps([b_hi])
-            ms, n = ctx.kernel_time()
-            t_ms += ms
-            t_n += n
-        ctx.set_option(pocs_amd.OPT_STORE_SAMPLES, 1)
-        nostore_ms = t_ms / max(t_n, 1)
-    ctx.set_option(pocs_amd.OPT_PROFILE, 0)
-    # shader clock under this load, in calls of their own: a sensor read goes through the driver and
-    # disturbs the GPU (kernels 15 % slower while it polls), so nothing else is measured meanwhile
-    board = None
-    if rank == 0 and not sharded and os.environ.get("POCS_NO_BOARD_PROBE") != "1":
-        try:
-            bus = getattr(torch.cuda.get_device_properties(local), "pci_bus_id", None)
-            probe = BoardProbe("%02x:00.0" % bus if isinstance(bus, int) else None)
-            probe.start()
-            t_end = time.perf_counter() + 0.4
-            while time.perf_counter() < t_end:
+            # one rank per GPU: two engines on two streams take the calls in turn, so one engine's
+            # kernel runs while the other's moments are in the all-reduce (parallel.run_gmm_pipelined)
+            n_eng = 2 if (path == "gmm" and len(chunks) >= 2 and not fused_exchange) else 1
+            if fused_exchange and path == "gmm" and len(chunks) >= 2 and os.environ.get("POCS_ENGINES") == "2":
+                # skew tolerance (DESIGN.md section 6): a second batch of runs in flight on a stream of its own -- while one
+                # engine's closers wait for the slowest rank's moments, the other engine's sampling blocks have the chip
+                n_eng = 2
+            # (every engine on a torch stream of its own: its launches, its collectives and its event waits in one order)
+            made = [make(b_hi, 0x5EED0001 + i, torch.cuda.Stream()) for i in range(n_eng)]
+            ctx = made[0][0]
+            engines = [e for _, e in made]
+            # POCS_ONEHOP=1: the library's own exchange (IPC-mapped slots, one hop over xGMI, sum + mixture
+            # advance in one small launch) instead of one RCCL all-reduce per waypoint from Python
+            onehop = path == "gmm" and xmode in ("1", "2")
+            run_onehop = par.run_gmm_onehop_fused if xmode == "2" else par.run_gmm_onehop
+            if onehop:
+                for e in engines:
+                    e.connect_onehop(dist if world > 1 else None, rank, world)
+
+            def run_steps(sizes):
+                p = 0.0
+                if path != "gmm":
+                    for _ in sizes:
+                        p = par.run_mc_sharded(engines[0], N, dist)      # one all_reduce of the hit count
+                    return p
+                for i in range(0, len(sizes), n_eng):
+                    group = sizes[i:i + n_eng]
+                    for e, b in zip(engines, group):
+                        if e.batch != b:
+                            e.set_batch(b)
+                    p = (run_onehop(engines[:len(group)]) if onehop else par.run_gmm_pipelined(engines[:len(group)], dist))[0]
+                return p
+
+        warm = [b_hi] * max(1, (warmup + batch - 1) // batch) + ([b_lo] if b_lo != b_hi else [])          # >= W untimed steps
+        if sharded and path == "gmm" and xmode in ("1", "2"):
+            # the one-hop exchange has passed a small probe; the warm-up is its first run at full size.  Should it fail
+            # there on any rank (the kernel's bounded wait gives up after 30 s and the call returns POCS_E_DEVICE), every
+            # rank switches to the RCCL path for the timed region -- agreed by a collective, so that nobody is left behind.
+            ok = 1.0
+            try:
+                run_steps(warm)
+            except pocs_amd.PocsError as exc:
+                print("rank %d: one-hop exchange failed in the warm-up: %s" % (rank, exc), file=sys.stderr)
+                ok = 0.0
+            ok = over_ranks([ok], dist.ReduceOp.MIN if dist is not None else None)[0]
+            if not ok:
+                xmode, onehop = "0", False
+                xstate["mode"], xstate["note"] = "0", "one-hop exchange failed in the warm-up at full size: fell back to RCCL"
+                run_steps(warm)
+        else:
+            run_steps(warm)
+
+        # The timed region, repeated: every repeat = EXACTLY `steps` steps between two fences (barrier + synchronize on
+        # both sides), its time the MAX over ranks.  The first repeat sizes the rest (the same number on every rank: it
+        # derives from the MAX): >= 10 repeats and about TIMED_TARGET_S of GPU time, at most 200.  The line carries
+        # the MEDIAN repeat (SURVEY 8d: "median of >= 10 runs after 2 warm-ups") with min / max beside it.
+        def timed_pass():
+            fence()
+            t0 = time.perf_counter()
+            p = run_steps(chunks)
+            fence()
+            d = time.perf_counter() - t0
+            if dist is not None:
+                d = over_ranks([d], dist.ReduceOp.MAX)[0]
+            return d, p
+        d0, prob = timed_pass()                        # (`probability` = the last run of the FIRST repeat: reproducible)
+        repeats = int(min(200, max(10, math.ceil(TIMED_TARGET_S / max(d0, 1e-6))))) if full else 3
+        dts = [d0] + [timed_pass()[0] for _ in range(repeats - 1)]
+        dt = statistics.median(dts)
+        evals = float(N) * W * steps
+        res = {"workload": workload, "W": W, "K": K, "path": path, "n_local": n_local, "N": N, "batch": batch, "chunks": chunks,
+               "prob": prob, "value": evals / dt, "ms_per_step": dt / steps * 1e3, "engines": len(engines) if engines else 1,
+               "xmode": xmode, "plan": plan,
+               "timing": {"repeats": repeats, "ms_per_step_median": dt / steps * 1e3, "ms_per_step_min": min(dts) / steps * 1e3,
+                          "ms_per_step_max": max(dts) / steps * 1e3, "timed_region_s": sum(dts),
+                          "protocol": "each repeat = `steps` steps between barrier + synchronize on both sides, MAX over ranks; "
+                                      "value and ms_per_step are the median repeat's"}}
+
+        # roofline of the dominant kernel: further calls with the hot kernel bracketed by hipEvents on
+        # the launch stream (eager launches; not part of `value`)
+        ctx.set_option(pocs_amd.OPT_PROFILE, 1)
+        ms_tot, n_launch, groups, waypoint_us = 0.0, 0, 1, None
+        for _ in range(max(1, min(len(chunks), 3))):
+            if engines:
+                if engines[0].batch != b_hi:
+                    engines[0].set_batch(b_hi)
+                if path == "gmm":
+                    (run_onehop(engines[:1]) if onehop else par.run_gmm_pipelined(engines[:1], dist))
+                else:
+                    par.run_mc_sharded(engines[0], N, dist)
+            else:
                 run_steps([b_hi])
-            board = probe.stop()
-        except Exception:                            # never let the side measurement break the bench line
-            board = None
+            ms, n = ctx.kernel_time()
+            ms_tot += ms
+            n_launch += n
+            if path == "gmm" and not engines and hasattr(ctx.lib, "pocs_get_sequence_time"):      # (an A/B library of an older commit has none)
+                seq_ms, groups = ctx.sequence_time()
+                waypoint_us = seq_ms * 1e3 / W
+        res["avg_ms"] = ms_tot / max(n_launch, 1)
+        res["groups"], res["waypoint_us"] = groups, waypoint_us
+        # sharded through the library's exchange: how long this rank's closers waited for the other ranks' moments in
+        # that last call, per (run, waypoint)
+        res["xwait"] = None
+        if engines and onehop and hasattr(ctx.lib, "pocs_get_exchange_wait"):
+            try:
+                res["xwait"] = ctx.exchange_wait_us()
+            except pocs_amd.PocsError:
+                res["xwait"] = None
+        # the same launches WITHOUT the sample stores (POCS_OPT_STORE_SAMPLES = 0: a product option, same arithmetic, same
+        # results): what the arithmetic alone takes on this box, to set beside what the stream alone would take at the fill
+        # rate -- the two meet at the board's power cap (DESIGN.md section 5); not part of `value`
+        res["nostore_ms"] = None
+        if full and path == "gmm" and not engines and os.environ.get("POCS_NO_STORE") != "1":
+            ctx.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
+            run_steps([b_hi])                            # (the graph / buffers of this variant)
+            t_ms, t_n = 0.0, 0
+            for _ in range(max(1, min(len(chunks), 2))):
+                run_steps([b_hi])
+                ms, n = ctx.kernel_time()
+                t_ms += ms
+                t_n += n
+            ctx.set_option(pocs_amd.OPT_STORE_SAMPLES, 1)
+            res["nostore_ms"] = t_ms / max(t_n, 1)
+        ctx.set_option(pocs_amd.OPT_PROFILE, 0)
+        # shader clock under this load, in calls of their own: a sensor read goes through the driver and
+        # disturbs the GPU (kernels 15 % slower while it polls), so nothing else is measured meanwhile
+        res["board"] = None
+        if full and rank == 0 and not sharded and os.environ.get("POCS_NO_BOARD_PROBE") != "1":
+            try:
+                bus = getattr(torch.cuda.get_device_properties(local), "pci_bus_id", None)
+                probe = BoardProbe("%02x:00.0" % bus if isinstance(bus, int) else None)
+                probe.start()
+                t_end = time.perf_counter() + 0.4
+                while time.perf_counter() < t_end:
+                    run_steps([b_hi])
+                res["board"] = probe.stop()
+            except Exception:                            # never let the side measurement break the bench line
+                res["board"] = None
+        res["copy_gbps"] = ctx.copy_bandwidth(1 << 30) if full else None      # measured streaming-copy ceiling of this GPU, same process
+        res["fill_gbps"] = ctx.fill_bandwidth(1 << 30) if full else None      # ... and the write-only one (the GMM kernels read nothing)
+        res["ranks_kernel_us"] = gather_ranks(res["avg_ms"] * 1e3) if dist is not None else None
+
+        # one run per call, no batch, no run-ahead: the rate of ONE runGMMEstimation / runSimulation command
+        # (SURVEY 8d defines the metric on one run* call; `value` above is the batched throughput)
+        res["single"] = None
+        if full and not sharded and os.environ.get("POCS_SKIP_SINGLE") != "1":
+            with pocs_amd.Context(local) as c1:
+                c1.configure(plan, env, K=K, N=N, seed=0x5EED0003)
+                c1.set_shard(0, n_local)
+                if args.mc_fused:
+                    c1.set_option(pocs_amd.OPT_MC_FUSED, 1)
+                run1 = c1.run_gmm_estimation if path == "gmm" else c1.run_simulation
+                for _ in range(3):
+                    run1()
+                torch.cuda.synchronize()
+                reps = 12
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    run1()
+                torch.cuda.synchronize()
+                res["single"] = float(n_local) * W * reps / (time.perf_counter() - t1)
+        if dist is not None:
+            fence()                                        # every rank is done with every rank's exchange buffer
+        for c, _ in made:
+            c.close()
+        return res
+
+    def exchange_text(res):
+        if not sharded or res["path"] != "gmm":
+            return "none (one GPU)" if not sharded else "none on the data path (MC: one all-reduce of the hit counts per run)"
+        return ("one-hop IPC slots in the sampling launch's tail (pocs_gmm_sample_exchange_local)" if res["xmode"] == "2"
+                else "one-hop IPC slots (pocs_gmm_exchange_local)" if res["xmode"] == "1"
+                else ("RCCL all-reduce per waypoint" + (" (%s)" % xstate["note"] if xstate["note"] else "")))
+
+    def exchange_wait(res):
+        """The closers' waits for the other ranks' moments: every rank's (min, median, max) over the (run, waypoint) pairs of
+        its last profiled call; over ranks the min of the mins, min / median / max of the medians, the max of the maxes."""
+        if dist is None or res["path"] != "gmm":
+            return None
+        mine = res["xwait"] if res["xwait"] is not None else (float("nan"),) * 3
+        cols = [gather_ranks(v) for v in mine]
+        if any(v != v for v in cols[1]):
+            return {"available": False, "why": "no in-kernel exchange on this path (%s)" % exchange_text(res)}
+        return {"available": True, "min_us": min(cols[0]), "median_us": {"min": min(cols[1]), "median": statistics.median(cols[1]), "max": max(cols[1]),
+                                                                        "per_rank": cols[1]}, "max_us": max(cols[2]),
+                "what": "in-kernel wall clock around the closer's poll for the world's rows, per (run, waypoint) of one call "
+                        "(pocs_get_exchange_wait); a rank that runs ahead of the others waits here",
+                "status": "measured on this run's ranks" + (" -- ALL ON ONE CARD (rehearsal): unmeasured on hardware with more than one GPU" if "POCS_FORCE_DEVICE" in os.environ or world == 1 else "")}
+
+    main_res = measure(args.workload, args.scaling, args.steps, args.warmup, args.batch, args.samples, True)
+    strong_rec = None
+    if (world > 1 and args.scaling == "weak" and args.workload == "cfg2" and not args.no_strong_record and not args.mc_fused):
+        # north_star's >= 6 x is about BASELINE configs[3] (cfg3's 10^7 samples x 500 waypoints, K = 8, SPLIT over the
+        # GPUs): the default curve above is weak scaling on cfg2, so a short pass of that workload rides along
+        sres = measure("cfg3", "strong", 16, 16, 16, args.samples, False)
+        kus = sres["ranks_kernel_us"] or []
+        strong_rec = {"workload": "cfg3 split over %d GPUs (BASELINE configs[3] at 8): %d samples per GPU per run of %d in total, W=%d, K=%d, %d runs per call"
+                                  % (world, sres["n_local"], sres["N"], sres["W"], sres["K"], sres["batch"]),
+                      "scaling": "strong", "value": sres["value"], "ms_per_step": sres["ms_per_step"], "repeats": sres["timing"]["repeats"],
+                      "ms_per_step_min": sres["timing"]["ms_per_step_min"], "ms_per_step_max": sres["timing"]["ms_per_step_max"],
+                      "probability": sres["prob"], "exchange": exchange_text(sres), "exchange_wait_us": exchange_wait(sres),
+                      "ranks_kernel_us": {"min": min(kus), "max": max(kus), "all": kus} if kus else None,
+                      "skew_us": (max(kus) - min(kus)) if kus else None,
+                      "one_gpu_reference": "the same workload on one GPU: `bench.py --workload cfg3 --steps 16 --warmup 16` (DESIGN.md section 7)"}
+
+    res = main_res
+    W, K, path, n_local, N, batch, chunks = res["W"], res["K"], res["path"], res["n_local"], res["N"], res["batch"], res["chunks"]
+    board, nostore_ms, groups, avg_ms = res["board"], res["nostore_ms"], res["groups"], res["avg_ms"]
+    copy_gbps, fill_gbps = res["copy_gbps"], res["fill_gbps"]
     kern = "k_gmm_step" if path == "gmm" else ("k_mc_fused" if args.mc_fused else "k_mc_step")
     bpe = BYTES_PER_EVAL_GMM if path == "gmm" else BYTES_PER_EVAL_MC
-    avg_ms = ms_tot / max(n_launch, 1)
-    # a call may be issued as G sub-batches whose launches run side by side (POCS_GMM_GROUPS, default 1): the events
+    # a call may be issued as G sub-batches whose launches run side by side (POCS_OPT_SUB_BATCHES, default 1): the events
     # bracket sub-batch 0's launches, each of which works on batch / G runs
     units = n_local * batch // max(groups, 1)       # evaluations one launch of the hot kernel processes
     achieved = (bpe * units) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -538,81 +729,80 @@ def main():
                 if rec.get("valu_insts_per_launch"):
                     valu_per_eval = rec["valu_insts_per_launch"] / (rec["evals_per_launch"] / 64.0)   # wave instructions per wave's 64 evaluations
                     valu_src = rec["source"].split(":")[0]
-    copy_gbps = ctx.copy_bandwidth(1 << 30)       # measured streaming-copy ceiling of this GPU, same process
-    fill_gbps = ctx.fill_bandwidth(1 << 30)       # ... and the write-only one (the GMM kernels read nothing)
     # What the kernel is actually limited by, in numbers: vector instructions per evaluation (counter record above) x
     # the evaluations per second inside the kernel, against the chip's wave64 issue rate -- 256 CUs x 4 SIMDs, one vector
     # instruction per SIMD every 4 cycles -- at the shader clock read live under this load (`board`), or at the peak clock.
-    limiter = None
+    mc_state_bytes = float(batch) * float((n_local + 1) & ~1) * 28.0
+    mc_resident = path == "mc" and not args.mc_fused and mc_state_bytes <= MC_CACHE_BYTES
     if path == "gmm":
         clock = (board or {}).get("sclk_MHz") or 2400.0
         issue_peak = 1024 * clock * 1e6 / 4.0
+        bound = "fp64-issue+power"
         limiter = {"kind": "FP64 vector issue (+ per-lane LDS table reads) and the all-write sample stream, coupled through the "
                            "board's power cap: neither alone (DESIGN.md section 5)",
                    "kernel_us_without_sample_stores": nostore_ms * 1e3 if nostore_ms else None,
-                   "stream_alone_us_at_fill_rate": (bpe * units / (fill_gbps * 1e9) * 1e6) if fill_gbps > 0 else None,
+                   "stream_alone_us_at_fill_rate": (bpe * units / (fill_gbps * 1e9) * 1e6) if (fill_gbps or 0) > 0 else None,
                    "valu_instr_per_eval": valu_per_eval, "clock_MHz": clock,
                    "clock_source": "amdgpu hwmon, live" if (board or {}).get("sclk_MHz") else "peak clock (no live reading)",
                    "valu_issue_frac": (valu_per_eval * (units / 64.0) / (avg_ms * 1e-3) / issue_peak) if (valu_per_eval and avg_ms > 0) else None,
                    "valu_source": valu_src,
                    "power_W": (board or {}).get("power_W"), "power_cap_W": (board or {}).get("power_cap_W")}
+    elif args.mc_fused:
+        bound = "fp64-issue"
+        limiter = {"kind": "FP64 vector issue: the particle stays in registers for the whole roll-out"}
+    elif mc_resident:
+        bound = "infinity-cache"
+        limiter = {"kind": "streaming through the 256 MB Infinity Cache: the batch's particle state (%.0f MB = %d runs x %d particles x 28 B) "
+                           "stays resident between two waypoint launches BY DESIGN (bench.py sizes the batch for it, pocs_host.hip picks the "
+                           "plain-access kernel), so the bytes per second below are not HBM traffic; the HBM-streaming form of the same kernel "
+                           "(k_mc_step<NT>) is what `--batch` beyond the cache measures (profiles/r04_mc_nt_*)" % (mc_state_bytes / 1e6, batch, n_local)}
     else:
-        limiter = {"kind": "HBM streaming (particle state read and written per waypoint; the hit counter only where a particle collides)"}
-    roofline = {"bound": "hbm", "limiter": limiter, "board": board,
-                "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and avg_ms > 0) else None,
-                "copy_GBps": copy_gbps, "frac_of_copy": achieved / copy_gbps if copy_gbps > 0 else None,
-                "fill_GBps": fill_gbps, "frac_of_fill": achieved / fill_gbps if fill_gbps > 0 else None,
+        bound = "hbm"
+        limiter = {"kind": "HBM streaming (particle state read and written per waypoint, non-temporal: %.0f MB of state per launch do not fit "
+                           "the 256 MB Infinity Cache; the hit counter only where a particle collides)" % (mc_state_bytes / 1e6)}
+    # `frac` is quoted against the HBM peak wherever the bytes can be HBM bytes: not for the cache-resident MC batch (null
+    # there: the guide gives no peak for the Infinity Cache) -- its achieved rate stands beside the copy ceiling instead
+    hbm_frac = None if mc_resident else achieved / HBM_PEAK_GBPS
+    roofline = {"bound": bound, "reported_against": None if mc_resident else "hbm", "limiter": limiter, "board": board,
+                "kernel": kern, "achieved": achieved, "peak": None if mc_resident else HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": hbm_frac, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and avg_ms > 0 and not mc_resident) else None,
+                "copy_GBps": copy_gbps, "frac_of_copy": achieved / copy_gbps if (copy_gbps or 0) > 0 else None,
+                "fill_GBps": fill_gbps, "frac_of_fill": achieved / fill_gbps if (fill_gbps or 0) > 0 else None,
                 "algorithmic_bytes_per_launch": bpe * units, "bytes_per_eval": bpe, "evals_per_launch": units,
-                "avg_kernel_us": avg_ms * 1e3, "concurrent_launches": groups, "waypoint_us": waypoint_us,
+                "avg_kernel_us": avg_ms * 1e3, "concurrent_launches": groups, "waypoint_us": res["waypoint_us"],
                 "evals_per_s_in_kernel": units / (avg_ms * 1e-3) if avg_ms > 0 else 0.0}
+    if path == "mc" and not args.mc_fused:
+        roofline["resident"] = "infinity-cache" if mc_resident else "hbm"
+        roofline["state_bytes_per_launch"] = mc_state_bytes
     if args.mc_fused:
         roofline["note"] = ("fused roll-out: the particle stays in registers for all waypoints, ~0 algorithmic bytes per evaluation "
                             "(28 B per particle per RUN) -- an FP64-issue kernel whose roofline is not HBM; read evals_per_s_in_kernel, "
                             "not frac (SURVEY 8d: reported separately from the streaming kernel)")
     if dist is not None:                               # every rank's kernel time, so that a scaling run explains itself
-        t = torch.zeros(world, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        t[rank] = avg_ms * 1e3
-        dist.all_reduce(t)
-        roofline["ranks_kernel_us"] = {"min": t.min().item(), "max": t.max().item(), "all": t.tolist()}
+        kus = res["ranks_kernel_us"]
+        roofline["ranks_kernel_us"] = {"min": min(kus), "max": max(kus), "all": kus}
+        roofline["skew_us"] = max(kus) - min(kus)      # slowest - fastest rank's mean launch of the hot kernel
 
-    # one run per call, no batch, no run-ahead: the rate of ONE runGMMEstimation / runSimulation command
-    # (SURVEY 8d defines the metric on one run* call; `value` above is the batched throughput)
-    single = None
-    if not sharded and os.environ.get("POCS_SKIP_SINGLE") != "1":
-        with pocs_amd.Context(local) as c1:
-            c1.configure(plan, env, K=K, N=N, seed=0x5EED0003)
-            c1.set_shard(0, n_local)
-            if args.mc_fused:
-                c1.set_option(pocs_amd.OPT_MC_FUSED, 1)
-            run1 = c1.run_gmm_estimation if path == "gmm" else c1.run_simulation
-            for _ in range(3):
-                run1()
-            torch.cuda.synchronize()
-            reps = 12
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                run1()
-            torch.cuda.synchronize()
-            single = float(n_local) * W * reps / (time.perf_counter() - t1)
-
+    t_gpu_part = time.perf_counter() - t_process
     if rank == 0:
         out = {
             "metric": "particle-waypoint evals/s (GMM+collision)" if path == "gmm" else "particle-waypoint evals/s (MC+collision)",
-            "value": value, "unit": "particle-waypoint evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "value": res["value"], "unit": "particle-waypoint evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "single_call_evals_per_s": single,
+            "numerics": "%s (%s)" % (NUMERICS, pocs_amd.load_library().pocs_version().decode()),
+            "timing": res["timing"],
+            "single_call_evals_per_s": res["single"],
             "config": {"workload": "%s: %s path, %s plan (%d waypoints), %d samples per GPU per run, K=%d, pr2test2 walls, PR2 0.668 m square footprint"
                                    % (args.workload, path.upper(), "bundled trajectory.dat/odometry.dat" if W == 56 else "resampled", W, n_local, K),
-                       "waypoints": W, "samples_per_gpu": n_local, "components": K, "probability": prob,
+                       "waypoints": W, "samples_per_gpu": n_local, "components": K, "probability": res["prob"],
                        "runs_per_launch": batch, "calls": chunks,
-                       "engines_in_flight": len(engines) if engines else 1,
-                       "exchange": ("one-hop IPC slots in the sampling launch's tail (pocs_gmm_sample_exchange_local)" if (sharded and path == "gmm" and xmode == "2")
-                                    else "one-hop IPC slots (pocs_gmm_exchange_local)" if (sharded and path == "gmm" and xmode == "1")
-                                    else ("RCCL all-reduce per waypoint" + (" (%s)" % xnote if xnote else "")) if (sharded and path == "gmm") else "none (one GPU)"),
+                       "engines_in_flight": res["engines"],
+                       "exchange": exchange_text(res),
                        "total_samples_per_run": N,
+                       "random_stream": "Philox4x32-7 for the mixture samples (SURVEY 8d wrote Philox4x32-10: a stated deviation, DESIGN.md section 4), "
+                                        "Philox4x32-10 for the host chain, the initial particles and the component counts",
                        "value_is": "batched throughput: `runs_per_launch` independent runs (the reference driver's 200-run loop) "
                                    "advance in lockstep per call; single_call_evals_per_s = one run per call",
                        "sanity_band": "collision model = this build's 2-D boxes, not OpenRAVE/ODE + PR2 mesh (not in the reference tree): "
@@ -620,16 +810,22 @@ def main():
                                       "0.935 / 0.64; same ordering, different level -- parity unpinned at that call site (DESIGN.md 8)"},
             "roofline": roofline,
         }
+        if sharded:
+            out["exchange_probe"] = xstate["probe"]
+            out["exchange_wait_us"] = None
+    if sharded:                                            # (collectives: every rank takes part)
+        xw = exchange_wait(res)
+        if rank == 0:
+            out["exchange_wait_us"] = xw
+            if strong_rec is not None:
+                out["strong"] = strong_rec
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(plan, env, K, W, path, args.cpu_evals)
+            out["cpu_baseline"] = cpu_baseline(res["plan"], env, K, W, path, args.cpu_evals, budget_s=max(2.0, CPU_BUDGET_FACTOR * t_gpu_part))
         sys.stdout.flush()
         os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if dist is not None:
-        fence()                                        # every rank is done with every rank's exchange buffer
-    for c, _ in made:
-        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -88,6 +88,13 @@ int pocs_send_command(pocs_ctx* ctx, const char* line, char* out, size_t cap);
                                       the previous waypoint in every block's head instead of tickets and a closing block (no one else
                                       is in flight to hide a closer behind): 10 % less time per waypoint, the same bits
                                       (tests/test_gpu_parity.py::test_lone_call_changes_no_bit).  0: the ticket form always. */
+#define POCS_OPT_SUB_BATCHES 8     /* 1 (default) or 2: a whole-run call's runs issued as that many sub-batches on streams of their own, so that one
+                                      sub-batch's launch tail is covered by the other's sampling blocks.  The moment sums are defined on a run's
+                                      virtual slices, not on the launch: no bit of any result changes.  Measured +0.5 % at 20 runs per call,
+                                      +2.5 % at 64 (three and four lost and are refused): off by default. */
+#define POCS_OPT_MC_NONTEMPORAL 9  /* -1 (default): k_mc_step streams past the caches when the batch's particle state (28 B per particle)
+                                      exceeds the 256 MB Infinity Cache and uses plain accesses when it fits; 0 / 1 force one form.
+                                      Same results either way. */
 int pocs_set_option(pocs_ctx* ctx, int option, long long value);
 
 /* ---- batches of independent runs (ours) --------------------------------------------------
@@ -170,6 +177,10 @@ long long pocs_copy_particles(pocs_ctx* ctx, double* xyt_aos, uint32_t* hits, lo
 int pocs_measure_copy_bandwidth(pocs_ctx* ctx, long long bytes, double* gbps);  /* read+write GB/s of a plain streaming copy on this GPU: the measured HBM ceiling */
 int pocs_measure_fill_bandwidth(pocs_ctx* ctx, long long bytes, double* gbps);  /* written GB/s of a plain streaming fill: the write-only ceiling (the GMM kernels read nothing) */
 int pocs_get_kernel_time(pocs_ctx* ctx, double* total_ms, long long* launches);  /* hot-kernel time of the last run with POCS_OPT_PROFILE=1 (of the launches on the context's stream) */
+int pocs_get_exchange_wait(pocs_ctx* ctx, double* min_median_max_us);  /* sharded GMM calls through the library's own exchange (pocs_gmm_exchange_local /
+                                                                          pocs_gmm_sample_exchange_local): how long the closers of the last begin..end sequence
+                                                                          waited for the other ranks' moments, over its (run, waypoint) pairs -- the first thing
+                                                                          to read when a multi-GPU run scales badly (ranks that drift apart show here) */
 int pocs_get_sequence_time(pocs_ctx* ctx, double* ms, int* concurrent);  /* POCS_OPT_PROFILE=1, whole-run GMM calls: first sampling launch -> end of the last one, and how many
                                                                             sub-batches of the call were in flight side by side (their launches overlap: DESIGN.md section 5) */
 

@@ -52,8 +52,8 @@ class Oracle:
         L.orc_run_gmm.restype = C.c_double
         L.orc_run_mc.restype = C.c_longlong
         L.orc_collides.restype = C.c_int
-        L.orc_log_unit32.restype = C.c_double
-        L.orc_log_unit32.argtypes = [C.c_uint32]
+        L.orc_radius2_unit32.restype = C.c_double
+        L.orc_radius2_unit32.argtypes = [C.c_uint32]
 
     def set_sum_order(self, order):
         """1 (default): the build's summation tree (numerics v7; the HIP path agrees bit for bit);
@@ -94,8 +94,8 @@ class Oracle:
         self.lib.orc_sincos_2pi_u32(C.c_uint32(w), C.byref(s), C.byref(c))
         return s.value, c.value
 
-    def log_unit32(self, w):
-        return self.lib.orc_log_unit32(C.c_uint32(w))
+    def radius2_unit32(self, w):
+        return self.lib.orc_radius2_unit32(C.c_uint32(w))
 
     def component_counts(self, K, state, seed, waypoint, n_total):
         state = np.ascontiguousarray(state, np.float64)

@@ -54,7 +54,7 @@
 #define ORC_STATE 16
 
 /* ------------------------------------------------------------------------------------------ */
-/* random streams (build spec "POCS numerics v7")                          */
+/* random streams (build spec "POCS numerics v8")                          */
 /* ------------------------------------------------------------------------------------------ */
 void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
   uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
@@ -193,9 +193,9 @@ void orc_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stre
   *spare = a[3];
 }
 
-/* ---- table-driven forms (hot path: mixture samples, footprint heading) ------------------------
- * lg[i] = {1/c_i rounded, -log(that)}, c_i = 1 + (i + 1/2)/512; sc[s] = {cos, sin} of the centre of
- * sector s of 256.  Built from the functions above, on first use. */
+/* ---- table-driven forms (hot path: mixture samples, footprint heading), numerics v8 ------------
+ * lg[i] = {1/c_i rounded, 2 log(that)}, c_i = 1 + (i + 1/2)/512; sc[s] = {cos, sin} of 2 pi s / 256, the
+ * sector boundaries.  Built from the functions above, on first use. */
 static double tab_lg[512][2], tab_sc[256][2];
 static int tab_ready = 0;
 static void tables(void) {
@@ -203,17 +203,20 @@ static void tables(void) {
   for (int i = 0; i < 512; ++i) {
     double c = 1.0 + ((double)i + 0.5) / 512.0;
     tab_lg[i][0] = 1.0 / c;
-    tab_lg[i][1] = -orc_log(tab_lg[i][0]);
+    tab_lg[i][1] = 2.0 * orc_log(tab_lg[i][0]);
   }
   for (int s = 0; s < 256; ++s) {
     double sn, cs;
-    orc_sincos_2pi_u32(((uint32_t)s << 24) + (1u << 23), &sn, &cs);
+    orc_sincos_2pi_u32((uint32_t)s << 24, &sn, &cs);
     tab_sc[s][0] = cs; tab_sc[s][1] = sn;
   }
   tab_ready = 1;
 }
 
-double orc_log_unit32(uint32_t w) {   /* log((w + 1) 2^-32): a uniform on (0, 1] with 2^32 levels */
+/* -2 log((w + 1) 2^-32), the squared Box-Muller radius of a uniform on (0, 1] with 2^32 levels:
+ * w + 1 = 2^e t; cell i of t; r = t / c_i - 1; -2 log t = 2 log(1/c_i) - 2 log1p(r), the latter as the
+ * degree-4 polynomial r (-2 + r (1 + r (-2/3 + r/2))); plus (e - 32) (-2 ln 2), one rounded product. */
+double orc_radius2_unit32(uint32_t w) {
   tables();
   double x = (double)w + 1.0;
   uint64_t bits;
@@ -224,12 +227,11 @@ double orc_log_unit32(uint32_t w) {   /* log((w + 1) 2^-32): a uniform on (0, 1]
   double t;
   memcpy(&t, &bits, 8);
   double r = fma(t, tab_lg[i][0], -1.0);
-  static const double co[4] = {-0.5, 1.0 / 3.0, -1.0 / 4.0, 1.0 / 5.0};
+  static const double co[4] = {-2.0, 1.0, -2.0 / 3.0, 0.5};
   double p = co[3];
   for (int k = 2; k >= 0; --k) p = fma(r, p, co[k]);
-  double l1p = fma(r * r, p, r);
-  double dk = (double)(e - 32);
-  return fma(dk, 6.93147180369123816490e-01, tab_lg[i][1]) + fma(dk, 1.90821492927058770002e-10, l1p);
+  double small = tab_lg[i][1] + r * p;
+  return fma((double)(e - 32), -1.386294361119890572454e+00, small);
 }
 
 static void sincos_small(double d, double* sd, double* cd) {
@@ -241,6 +243,7 @@ static void sincos_small(double d, double* sd, double* cd) {
   *cd = fma(z, pc, 1.0);
 }
 
+/* the Box-Muller angle of a word: table entry of its top 8 bits, the low 24 bits a signed offset from it */
 void orc_sincos_2pi_u32_tab(uint32_t w, double* s, double* c) {
   tables();
   int sec = (int)(w >> 24);
@@ -255,13 +258,12 @@ void orc_sincos_2pi_u32_tab(uint32_t w, double* s, double* c) {
 
 void orc_sincos_tab(double x, double* s, double* c) {
   tables();
-  double fn = floor(x * 4.07436654315252084757e+01);      /* 256 / (2 pi) */
+  double fn = rint(x * 4.07436654315252084757e+01);       /* 256 / (2 pi) */
   int n = (int)fn;
-  double d = fma(-fn, 2.45436926052207127213e-02, x);     /* pi/128 in three pieces */
-  d = fma(-fn, 9.49546954109994683843e-13, d);
-  d = fma(-fn, 3.15979101374367286178e-23, d);
+  double d = fma(-fn, 2.45436926052207127213e-02, x);     /* pi/128 = its first 34 bits + the rest */
+  d = fma(-fn, 9.495469541415925389561e-13, d);
   double sd, cd;
-  sincos_small(d - 1.22718463030851293594e-02, &sd, &cd); /* half a sector */
+  sincos_small(d, &sd, &cd);
   int sec = n & 255;
   double C = tab_sc[sec][0], S = tab_sc[sec][1];
   *s = fma(S, cd, C * sd);
@@ -270,7 +272,7 @@ void orc_sincos_tab(double x, double* s, double* c) {
 
 /* Box-Muller pair of the mixture sampler: radius word wr, angle word wa. */
 void orc_normal_pair_w2(uint32_t wr, uint32_t wa, double* n0, double* n1) {
-  double radius = sqrt(fabs(-2.0 * orc_log_unit32(wr)));   /* |.|: at u = 1 the log may be a rounding error above 0 */
+  double radius = sqrt(fabs(orc_radius2_unit32(wr)));      /* |.|: at u = 1 the value is a rounding error around 0 */
   double s, c;
   orc_sincos_2pi_u32_tab(wa, &s, &c);
   *n0 = radius * c;

@@ -8,7 +8,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libpocs.so"
 SOURCES = ["pocs_kernels.hip", "pocs_host.hip"]
-HEADERS = ["pocs_math.h", "pocs_model.h", "pocs_collide.h", "pocs_kernels.h", "../../include/pocs.h"]
+HEADERS = ["pocs_math.h", "pocs_model.h", "pocs_collide.h", "pocs_kernels.h", "pocs_command.hpp", "../../include/pocs.h"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 

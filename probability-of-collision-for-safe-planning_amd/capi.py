@@ -14,6 +14,7 @@ from . import build as _build
 POCS_OK = 0
 E_ARG, E_ORDER, E_STATE, E_DEVICE, E_UNKNOWN_COMMAND, E_BUFFER = -1, -2, -3, -4, -5, -6
 OPT_STORE_SAMPLES, OPT_MC_FUSED, OPT_USE_GRAPH, OPT_PROFILE, OPT_RUN_AHEAD, OPT_PERSISTENT, OPT_LONE_CALL = 1, 2, 3, 4, 5, 6, 7
+OPT_SUB_BATCHES, OPT_MC_NONTEMPORAL = 8, 9
 NMOM = 11
 
 _dp = C.POINTER(C.c_double)
@@ -73,6 +74,7 @@ SIGNATURES = {
     "pocs_measure_fill_bandwidth": (C.c_int, [_vp, C.c_longlong, _dp]),
     "pocs_get_kernel_time": (C.c_int, [_vp, _dp, C.POINTER(C.c_longlong)]),
     "pocs_get_sequence_time": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
+    "pocs_get_exchange_wait": (C.c_int, [_vp, _dp]),
 }
 
 _lib = None
@@ -405,6 +407,13 @@ class Context:
         ms, g = C.c_double(0.0), C.c_int(1)
         self._chk(self.lib.pocs_get_sequence_time(self.h, C.byref(ms), C.byref(g)))
         return ms.value, g.value
+
+    def exchange_wait_us(self):
+        """(min, median, max) over the (run, waypoint) pairs of the last sharded begin..end sequence of how long the
+        closers waited for the other ranks' moments, in microseconds (the library's own exchange only)."""
+        v = (C.c_double * 3)()
+        self._chk(self.lib.pocs_get_exchange_wait(self.h, v))
+        return v[0], v[1], v[2]
 
     def kernel_time(self):
         ms, n = C.c_double(), C.c_longlong()

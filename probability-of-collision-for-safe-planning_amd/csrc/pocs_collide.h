@@ -137,13 +137,15 @@ POCS_HD void pocs_pair_collides(const double x[2], const double y[2], const doub
 //   radius at t = +-atan(ry / rx) + k pi: with no peak inside the range the maximum sits at an end.
 // k_gmm_step's culling uses it to give the records it keeps a broad phase that fits the task's headings
 // (gmm_cull); tests/test_product_host_vs_oracle.py scans f densely against it.
-POCS_HD double pocs_footprint_extent(double rx, double ry, double lo, double hi) {
-  const double rr = sqrt(rx * rx + ry * ry), PI = 3.14159265358979323846;
+//   rr = the bounding radius sqrt(rx^2 + ry^2), phi = atan2(ry, rx): constants of the footprint, computed once on the
+//   host for the kernels (every block of every launch culls: a square root, an arc tangent and four divisions less
+//   in each of them)
+POCS_HD double pocs_footprint_extent_pre(double rx, double ry, double rr, double phi, double lo, double hi) {
+  const double PI = 3.14159265358979323846, INV_PI = 0.318309886183790671538;
   if (!(hi - lo < PI)) return rr;
-  const double phi = atan2(ry, rx);
   for (int sgn = -1; sgn <= 1; sgn += 2) {
     const double s = sgn * phi;
-    if (ceil((lo - s) / PI) <= floor((hi - s) / PI)) return rr;         // a peak inside the range
+    if (ceil((lo - s) * INV_PI) <= floor((hi - s) * INV_PI)) return rr;   // a peak inside the range
   }
   double sn, cs;
   pocs_sincos(lo, &sn, &cs);
@@ -151,4 +153,7 @@ POCS_HD double pocs_footprint_extent(double rx, double ry, double lo, double hi)
   pocs_sincos(hi, &sn, &cs);
   const double fb = fma(rx, fabs(cs), ry * fabs(sn));
   return fmin(rr, fmax(fa, fb) * (1.0 + 1e-9) + 1e-12);
+}
+POCS_HD double pocs_footprint_extent(double rx, double ry, double lo, double hi) {
+  return pocs_footprint_extent_pre(rx, ry, sqrt(rx * rx + ry * ry), atan2(ry, rx), lo, hi);
 }

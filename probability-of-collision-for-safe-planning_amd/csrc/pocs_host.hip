@@ -19,11 +19,13 @@
 #include <vector>
 #include <map>
 #include <chrono>
+#include <algorithm>
 
 #include "../../include/pocs.h"
 #include "pocs_kernels.h"
+#include "pocs_command.hpp"
 
-#define POCS_VERSION_STRING "pocs-mi355x 0.3 (gfx950; numerics v7)"
+#define POCS_VERSION_STRING "pocs-mi355x 0.4 (gfx950; numerics v8: summation tree of 512-pair chunks, 256 virtual slices)"
 
 namespace {
 
@@ -67,7 +69,7 @@ struct pocs_ctx {
   std::vector<double> boxes;             // M x 5
   bool have_obstacles = false;           // pocs_set_obstacles / addObstacle / clearObstacles was called at least once
   long long shard_first = -1, shard_count = -1;
-  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0, opt_lone = 1;
+  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0, opt_lone = 1, opt_groups = 1, opt_mc_nt = -1;
   unsigned long long epoch = 0;          // bumped by every setter; part of the graph cache key
   int batch = 1;                         // independent GMM estimations advanced in lockstep per call
   // run-ahead (POCS_OPT_RUN_AHEAD): with batch == 1 a run* call evaluates the next `run_ahead` runs
@@ -173,16 +175,8 @@ int ensure(pocs_ctx* c, DevBuf& b, size_t bytes) {
   return POCS_OK;
 }
 
-int grid_blocks(long long count, int block, int default_bpc) {
-  // One block per `block` evaluations up to `bpc` resident blocks per CU (256 CUs), grid-stride
-  // beyond that.  POCS_BLOCKS_PER_CU overrides the default for tuning sweeps.
-  static int env_bpc = -1;
-  if (env_bpc < 0) {
-    const char* e = getenv("POCS_BLOCKS_PER_CU");
-    env_bpc = e ? atoi(e) : 0;
-    if (env_bpc < 0 || env_bpc > 8) env_bpc = 0;
-  }
-  const int bpc = env_bpc ? env_bpc : default_bpc;
+int grid_blocks(long long count, int block, int bpc) {
+  // One block per `block` evaluations up to `bpc` resident blocks per CU (256 CUs), grid-stride beyond that.
   long long nb = (count + block - 1) / block;
   if (nb < 1) nb = 1;
   if (nb > 256LL * bpc) nb = 256LL * bpc;
@@ -196,18 +190,8 @@ int grid_blocks(long long count, int block, int default_bpc) {
 // these: `upb` is the smallest number that fits the launch into 512 blocks (256 below 8 runs: fewer,
 // fatter blocks amortise head and tail better when the launch is short anyway), so every block of a launch
 // has the same amount of work whatever the number of runs (20 runs x 256 slices = 512 blocks x 10).
-// POCS_GMM_BLOCKS overrides the block budget for sweeps.
-#ifndef POCS_GMM_SKEW_DEFAULT
-#define POCS_GMM_SKEW_DEFAULT 500
-#endif
-struct GmmGeometry { long long chunks; int vs_shift; int upb; int upb2; int split; int blocks; };
+struct GmmGeometry { long long chunks; int vs_shift; int upb; int blocks; };
 GmmGeometry gmm_geometry(long long count, int runs, int K, int groups = 1) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("POCS_GMM_BLOCKS");
-    forced = e ? atoi(e) : 0;
-    if (forced < 0 || forced > 4096) forced = 0;
-  }
   const int tb = POCS_GMM_BLOCK_OF(K);
   const long long npairs = (count + 1) / 2;
   GmmGeometry g;
@@ -218,35 +202,10 @@ GmmGeometry gmm_geometry(long long count, int runs, int K, int groups = 1) {
   if (runs < 1) runs = 1;
   const long long units = (long long)runs << g.vs_shift;
   // (`groups` launches share the chip: each gets its share of the resident blocks)
-  long long budget = (runs * groups >= 8 ? POCS_NUM_CUS * POCS_GMM_BLOCKS_PER_CU : POCS_NUM_CUS) / groups;
-  if (forced) budget = forced;
+  const long long budget = (runs * groups >= 8 ? POCS_NUM_CUS * POCS_GMM_BLOCKS_PER_CU : POCS_NUM_CUS) / groups;
   g.upb = (int)((units + budget - 1) / budget);
   if (g.upb > (1 << g.vs_shift)) g.upb = 1 << g.vs_shift;           // a block's range touches at most two runs
   g.blocks = (int)((units + g.upb - 1) / g.upb);
-  g.upb2 = g.upb; g.split = g.blocks;
-  // Two blocks per CU: the chip places blocks 0..255 first and 256..511 beside them, and a SIMD's arbiter prefers
-  // its OLDER waves whenever priorities tie -- measured (per-block stamps, 10^6 samples, K = 3), the second half of
-  // the grid needs 14 % longer for the same units at 20 runs per launch and 17 % at 64, launch after launch, and the
-  // launch ends with the slowest block.  So the halves get unequal shares: the first 256 blocks `upb` units each,
-  // the rest `upb2`, in the ratio of their measured paces (POCS_GMM_SKEW, per mille of a CU's units that go to its
-  // first block; 500 = even).  Which block adds which unit changes no bit: a unit's row is the unit's alone.
-  static int skew = -1;
-  if (skew < 0) {
-    const char* e = getenv("POCS_GMM_SKEW");
-    skew = e ? atoi(e) : POCS_GMM_SKEW_DEFAULT;
-    if (skew < 500 || skew > 750) skew = 500;
-  }
-  if (!forced && groups == 1 && skew > 500 && g.blocks == POCS_NUM_CUS * 2 && units >= 4LL * POCS_NUM_CUS) {
-    const long long per_cu = (units + POCS_NUM_CUS - 1) / POCS_NUM_CUS;
-    int ua = (int)((per_cu * skew + 500) / 1000);
-    if (ua > (1 << g.vs_shift)) ua = 1 << g.vs_shift;
-    const long long rest = units - (long long)POCS_NUM_CUS * ua;
-    if (ua >= 1 && rest > 0) {
-      const int ub = (int)((rest + POCS_NUM_CUS - 1) / POCS_NUM_CUS);
-      g.upb = ua; g.upb2 = ub; g.split = POCS_NUM_CUS;
-      g.blocks = POCS_NUM_CUS + (int)((rest + ub - 1) / ub);
-    }
-  }
   return g;
 }
 int grid_for_mc(long long count, int runs = 1) {                                      // MC kernels, per run
@@ -254,13 +213,7 @@ int grid_for_mc(long long count, int runs = 1) {                                
   // stream: measured 0.78 of the HBM peak against 0.67 with three, 0.70 with eight
   const int one = grid_blocks(count, POCS_BLOCK, 6);
   if (runs <= 1) return one;
-  static int total = -1;
-  if (total < 0) {
-    const char* e = getenv("POCS_MC_GRID_TOTAL");               // sweeps
-    total = e ? atoi(e) : 1536;
-    if (total < 256 || total > 8192) total = 1536;
-  }
-  int per = total / runs;
+  int per = 1536 / runs;                             // the batch's launches share the chip's 6 x 256 resident blocks
   if (per < 1) per = 1;
   return per < one ? per : one;
 }
@@ -468,11 +421,12 @@ int gmm_shard(pocs_ctx* c, long long* first, long long* count) {
 }
 
 // The synchronisation words of one call (pocs_kernels.h): [1] give-up code, [0], [2..3] pad, then the
-// tickets [R][W]; a block of its own, a multiple of 16 bytes, zeroed by ONE memset node at the head of
-// every call.
+// tickets [R][W], then -- sharded runs -- the closers' exchange waits [R][W]; a block of its own, a multiple of
+// 16 bytes, zeroed by ONE memset at the head of every call.
 size_t sync_ticket_offset(const pocs_ctx*) { return 4; }
+size_t sync_xwait_offset(const pocs_ctx* c) { return sync_ticket_offset(c) + (size_t)c->batch * (size_t)(c->W > 0 ? c->W : 1); }
 size_t sync_words(const pocs_ctx* c) {
-  const size_t n = sync_ticket_offset(c) + (size_t)c->batch * (size_t)(c->W > 0 ? c->W : 1);
+  const size_t n = sync_xwait_offset(c) + (size_t)c->batch * (size_t)(c->W > 0 ? c->W : 1);      // tickets, then the exchange waits
   return (n + 3) & ~(size_t)3;
 }
 
@@ -599,13 +553,15 @@ void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long
   a->partial_prev = a->partial;
   a->sync = (unsigned*)c->d_ticket.p;
   a->ticket = a->sync + sync_ticket_offset(c);
+  a->xwait = a->sync + sync_xwait_offset(c);
   const GmmGeometry geo = gmm_geometry(count, run_cnt, c->K, groups);
-  a->chunks = geo.chunks; a->vs_shift = geo.vs_shift; a->upb = geo.upb; a->upb2 = geo.upb2; a->split = geo.split; a->blocks = geo.blocks;
+  a->chunks = geo.chunks; a->vs_shift = geo.vs_shift; a->upb = geo.upb; a->blocks = geo.blocks;
   a->run_lo = run_lo; a->run_cnt = run_cnt;
   a->x = (double*)c->d_sx.p; a->y = (double*)c->d_sy.p; a->th = (double*)c->d_st.p;
   a->flags = (int16_t*)c->d_flags.p;
   a->first = first; a->count = count; a->n_total = c->num_gmm;
   a->fp = c->fp; a->M = (int)(c->boxes.size() / 5);
+  a->fp_rr = sqrt(c->fp.hx * c->fp.hx + c->fp.hy * c->fp.hy); a->fp_phi = atan2(c->fp.hy, c->fp.hx);
   a->waypoint = w; a->store = c->opt_store ? 1 : 0;
   a->sample_stride = sample_stride_of(count);
   a->nruns = c->batch; a->W = c->W;
@@ -621,13 +577,9 @@ int enqueue_advance(pocs_ctx* c, int w) {
 }
 
 // One run per call (no batch, no run-ahead) on one GPU: the launches close the previous waypoint in their heads
-// (k_gmm_step, "LONE"): 30.6 -> 27.5 us per waypoint at 10^6 samples, K = 3 (MI355X).  POCS_OPT_LONE_CALL = 0 (or
-// POCS_LONE=0 in the environment, for A/B runs) keeps the ticket-and-closer form; the results are the same bits.
-bool lone_call(const pocs_ctx* c) {
-  static int allowed = -1;
-  if (allowed < 0) { const char* e = getenv("POCS_LONE"); allowed = (e && atoi(e) == 0) ? 0 : 1; }
-  return allowed && c->opt_lone && c->batch == 1 && !c->ext_moments;
-}
+// (k_gmm_step, "LONE"): 30.6 -> 27.5 us per waypoint at 10^6 samples, K = 3 (MI355X).  POCS_OPT_LONE_CALL = 0
+// keeps the ticket-and-closer form; the results are the same bits.
+bool lone_call(const pocs_ctx* c) { return c->opt_lone && c->batch == 1 && !c->ext_moments; }
 void set_lone(pocs_ctx* c, pocs_gmm_launch* a, int w) {
   const size_t half = ((size_t)1 << a->vs_shift) * c->K * POCS_NMOM;      // one run's rows
   a->lone = 1;
@@ -661,18 +613,12 @@ size_t gmm_hot_launches(const pocs_ctx* c) { return (size_t)c->W; }
 // "summation tree"), so a split changes no bit of any result.  One by default: measured on MI355X (round 3, 10^6
 // samples, K = 3, same box) two sub-batches gave +0.5 % at 20 runs per call and +2.5 % at 64, three and four lost --
 // the launches' tails are mostly blocks of unequal speed, which a second kernel in flight does not fix.
-// POCS_GMM_GROUPS = 1..4 overrides (sweeps; tests/test_gpu_parity.py checks the bits).
+// POCS_OPT_SUB_BATCHES = 1 (default) or 2 (tests/test_gpu_parity.py checks the bits).
 int gmm_groups(const pocs_ctx* c) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("POCS_GMM_GROUPS");
-    forced = e ? atoi(e) : 0;
-    if (forced < 0 || forced > 4) forced = 0;
-  }
   if (c->ext_moments) return 1;
-  int g = forced ? forced : 1;
+  int g = (int)c->opt_groups;
   if (g > c->batch) g = c->batch;
-  return g;
+  return g < 1 ? 1 : g;
 }
 
 // The launches of a whole-run call: what the hipGraph holds.  KERNEL NODES ONLY -- the ticket reset ahead of
@@ -765,10 +711,13 @@ std::string config_key(const pocs_ctx* c, long long first, long long count, cons
 
 int run_gmm_full(pocs_ctx* c, double* probability) {
   if (!probability) return fail(c, POCS_E_ARG, "null output");
-  static const bool call_times = getenv("POCS_CALL_TIMES") != nullptr;     // tuning: host-side phases of a call on stderr
+#if defined(POCS_TUNING) && defined(POCS_CALL_TIMES)                          // tuning build: host-side phases of a call on stderr
   const auto t_in = std::chrono::steady_clock::now();
-  auto lap = [&](const char* what) { if (call_times) fprintf(stderr, "[call] %s +%.1f us\n", what,
+  auto lap = [&](const char* what) { fprintf(stderr, "[call] %s +%.1f us\n", what,
       std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count()); };
+#else
+  auto lap = [](const char*) {};
+#endif
   if (int r = gmm_prepare(c)) return r;
   long long first, count;
   if (int r = gmm_shard(c, &first, &count)) return r;
@@ -848,8 +797,7 @@ int enqueue_mc_all(pocs_ctx* c, long long first, long long count, bool prof) {
   // 28 B of state per particle.  Up to 8 x 10^6 particles (224 MB) the state of a batch stays in the
   // 256 MB Infinity Cache between waypoint launches; past that the launches stream from HBM whatever
   // they do, and non-temporal accesses then stream faster (16 x 10^6: 148 us instead of 189 us)
-  a.nontemporal = ((double)R * (double)a.stride * 28.0 > 232.0e6) ? 1 : 0;
-  if (const char* e = getenv("POCS_MC_NT")) a.nontemporal = atoi(e) ? 1 : 0;          // sweeps
+  a.nontemporal = c->opt_mc_nt >= 0 ? (int)c->opt_mc_nt : (((double)R * (double)a.stride * 28.0 > 232.0e6) ? 1 : 0);
   a.mu0[0] = c->traj[0]; a.mu0[1] = c->traj[W]; a.mu0[2] = c->traj[2 * W];
   if (!pocs_chol3_lower(c->cov0, a.L0)) return fail(c, POCS_E_ARG, "initial covariance is not positive definite");
   if (c->opt_fused) {
@@ -929,21 +877,6 @@ int run_mc_local(pocs_ctx* c) {
 // ------------------------------------------------------------------------------------------
 // text dispatcher
 // ------------------------------------------------------------------------------------------
-bool split_numbers(const char* s, std::vector<double>* out) {
-  out->clear();
-  while (*s) {
-    while (*s == ' ' || *s == '\t' || *s == '\n' || *s == '\r') ++s;
-    if (!*s) break;
-    char* end = nullptr;
-    const double v = strtod(s, &end);
-    if (end == s) return false;
-    if (*end && *end != ' ' && *end != '\t' && *end != '\n' && *end != '\r') return false;
-    out->push_back(v);
-    s = end;
-  }
-  return true;
-}
-
 int put(pocs_ctx* c, char* out, size_t cap, const char* text) {
   if (!out || cap == 0) return POCS_OK;
   const size_t n = strlen(text);
@@ -951,8 +884,6 @@ int put(pocs_ctx* c, char* out, size_t cap, const char* text) {
   memcpy(out, text, n + 1);
   return POCS_OK;
 }
-
-bool is_integer(double v) { return v == floor(v) && fabs(v) < 9.0e15; }
 
 const char* kHelp =
     "MyCommand        This is an example command\n"
@@ -1014,12 +945,12 @@ int pocs_create(pocs_ctx** out, int device) {
   return POCS_OK;
 }
 
-#if defined(POCS_STAMPS)
+#if defined(POCS_TUNING) && defined(POCS_STAMPS)
 void pocs_stamps_report();
 #endif
 void pocs_destroy(pocs_ctx* c) {
   if (!c) return;
-#if defined(POCS_STAMPS)
+#if defined(POCS_TUNING) && defined(POCS_STAMPS)
   if (c->own_stream) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); pocs_stamps_report(); }
 #endif
   if (c->own_stream) {
@@ -1191,6 +1122,14 @@ int pocs_set_option(pocs_ctx* c, int option, long long value) {
       if (value) return fail(c, POCS_E_ARG, "POCS_OPT_PERSISTENT: the queue-driven kernel has been retired (DESIGN.md section 5)");
       break;
     case POCS_OPT_LONE_CALL: c->opt_lone = value ? 1 : 0; break;
+    case POCS_OPT_SUB_BATCHES:
+      if (value < 1 || value > 2) return fail(c, POCS_E_ARG, "sub-batches %lld outside 1..2 (three and four lost: DESIGN.md section 5)", value);
+      c->opt_groups = value;
+      break;
+    case POCS_OPT_MC_NONTEMPORAL:
+      if (value < -1 || value > 1) return fail(c, POCS_E_ARG, "POCS_OPT_MC_NONTEMPORAL takes -1 (by size), 0 or 1");
+      c->opt_mc_nt = value;
+      break;
     case POCS_OPT_RUN_AHEAD:
       if (value < 0 || value > 256) return fail(c, POCS_E_ARG, "run-ahead %lld outside 0..256", value);
       c->run_ahead = (int)value;                     // 0 = sized per call (ra_depth)
@@ -1674,6 +1613,23 @@ int pocs_get_sequence_time(pocs_ctx* c, double* ms, int* concurrent) {
   return POCS_OK;
 }
 
+// Sharded GMM calls through the library's own exchange: how long the closers of the last begin..end sequence waited
+// for the other ranks' moments, over its (run, waypoint) pairs: min, median, max in microseconds.
+int pocs_get_exchange_wait(pocs_ctx* c, double* min_median_max_us) {
+  if (!c || !min_median_max_us) return POCS_E_ARG;
+  if (c->W < 1 || c->batch < 1 || !c->d_ticket.p) return fail(c, POCS_E_STATE, "no GMM call yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)c->batch * (size_t)c->W;
+  std::vector<unsigned> v(n);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int r = copy_out(c, v.data(), (unsigned*)c->d_ticket.p + sync_xwait_offset(c), n * sizeof(unsigned), sizeof(unsigned), sizeof(unsigned))) return r;
+  std::sort(v.begin(), v.end());
+  min_median_max_us[0] = 0.01 * v.front();
+  min_median_max_us[1] = 0.01 * ((n & 1) ? v[n / 2] : 0.5 * ((double)v[n / 2 - 1] + (double)v[n / 2]));
+  min_median_max_us[2] = 0.01 * v.back();
+  return POCS_OK;
+}
+
 int pocs_get_kernel_time(pocs_ctx* c, double* total_ms, long long* launches) {
   if (!c) return POCS_E_ARG;
   if (total_ms) *total_ms = c->prof_ms;
@@ -1681,82 +1637,51 @@ int pocs_get_kernel_time(pocs_ctx* c, double* total_ms, long long* launches) {
   return POCS_OK;
 }
 
+// The text channel: the grammar (names, token counts, order rules) lives in pocs_command.hpp -- host only, fuzzed
+// under sanitizers on the CPU -- and this is the dispatch of a parsed line to the typed setters above.
 int pocs_send_command(pocs_ctx* c, const char* line, char* out, size_t cap) {
   if (!c || !line) return POCS_E_ARG;
   if (out && cap) out[0] = 0;
-  while (*line == ' ' || *line == '\t') ++line;
-  const char* sp = line;
-  while (*sp && *sp != ' ' && *sp != '\t' && *sp != '\n') ++sp;
-  const std::string name(line, sp);
-  const char* rest = sp;
-  std::vector<double> v;
-  auto numbers = [&](size_t want) -> int {
-    if (!split_numbers(rest, &v)) return fail(c, POCS_E_ARG, "%s: malformed number", name.c_str());
-    if (v.size() != want) return fail(c, POCS_E_ARG, "%s: expected %zu values, got %zu", name.c_str(), want, v.size());
-    return POCS_OK;
-  };
-  auto one_int = [&](long long* n) -> int {
-    if (int r = numbers(1)) return r;
-    if (!is_integer(v[0])) return fail(c, POCS_E_ARG, "%s: integer expected", name.c_str());
-    *n = (long long)v[0];
-    return POCS_OK;
-  };
-  char buf[64];
-  long long n = 0;
-  if (name == "MyCommand") return put(c, out, cap, "output");                 // mcsimplugin.cpp:225-231
-  if (name == "ArmaCommand") return POCS_OK;                                   // :189-223 (Armadillo demo) -> no-op
-  if (name == "help") return put(c, out, cap, kHelp);
-  if (name == "setAlphas") {                                                   // :174-187
-    if (!split_numbers(rest, &v)) return fail(c, POCS_E_ARG, "setAlphas: malformed number");
-    return pocs_set_alphas(c, v.data(), (int)v.size());
+  const pocs_cmd::Shape shape = {c->num_landmarks, c->W};
+  const pocs_cmd::Parsed p = pocs_cmd::parse(line, shape);
+  if (p.err) return fail(c, p.err, "%s", p.msg.c_str());
+  const std::vector<double>& v = p.v;
+  switch (p.id) {
+    case pocs_cmd::kMyCommand: return put(c, out, cap, "output");                   // mcsimplugin.cpp:225-231
+    case pocs_cmd::kArmaCommand: return POCS_OK;                                     // :189-223 (Armadillo demo) -> no-op
+    case pocs_cmd::kHelp: return put(c, out, cap, kHelp);
+    case pocs_cmd::kSetAlphas: return pocs_set_alphas(c, v.data(), (int)v.size());   // :174-187
+    case pocs_cmd::kSetQ: return pocs_set_q(c, v[0]);
+    case pocs_cmd::kSetNumLandmarks: return pocs_set_num_landmarks(c, (int)p.n);
+    case pocs_cmd::kSetLandmarks: return pocs_set_landmarks(c, v.data(), c->num_landmarks);
+    case pocs_cmd::kSetNumParticles: return pocs_set_num_particles(c, p.n);
+    case pocs_cmd::kSetInitialCovariance: return pocs_set_initial_covariance(c, v.data());
+    case pocs_cmd::kSetPathLength: return pocs_set_path_length(c, (int)p.n);
+    case pocs_cmd::kSetTrajectory: return pocs_set_trajectory(c, v.data(), c->W);
+    case pocs_cmd::kSetOdometry: return pocs_set_odometry(c, v.data(), c->W - 1);
+    case pocs_cmd::kSetNumGaussians: return pocs_set_num_gaussians(c, (int)p.n);
+    case pocs_cmd::kSetNumGMMSamples: return pocs_set_num_gmm_samples(c, p.n);
+    case pocs_cmd::kSetSeed: return pocs_set_seed(c, (uint64_t)p.seed);
+    case pocs_cmd::kSetFootprint: return pocs_set_footprint(c, v[0], v[1], v[2], v[3]);
+    case pocs_cmd::kAddObstacle: {
+      std::vector<double> b = c->boxes;
+      b.insert(b.end(), v.begin(), v.end());
+      return pocs_set_obstacles(c, b.data(), (int)(b.size() / 5));
+    }
+    case pocs_cmd::kClearObstacles: return pocs_set_obstacles(c, nullptr, 0);
+    case pocs_cmd::kSetBatch: return pocs_set_batch(c, (int)p.n);
+    case pocs_cmd::kSetRunAhead: return pocs_set_option(c, POCS_OPT_RUN_AHEAD, p.n);
+    case pocs_cmd::kRunSimulation: case pocs_cmd::kRunGMMEstimation: {               // :75-81, :66-72
+      double prob = 0.0;
+      const int r = (p.id == pocs_cmd::kRunSimulation) ? pocs_run_simulation(c, &prob) : pocs_run_gmm_estimation(c, &prob);
+      if (r) return r;
+      char buf[64];
+      snprintf(buf, sizeof buf, "%.17g", prob);
+      return put(c, out, cap, buf);
+    }
+    case pocs_cmd::kUnknown: break;
   }
-  if (name == "setQ") { if (int r = numbers(1)) return r; return pocs_set_q(c, v[0]); }
-  if (name == "setNumLandmarks") { if (int r = one_int(&n)) return r; return pocs_set_num_landmarks(c, (int)n); }
-  if (name == "setLandmarks") {
-    if (c->num_landmarks < 0) return fail(c, POCS_E_ORDER, "setLandmarks before setNumLandmarks");
-    if (int r = numbers((size_t)2 * c->num_landmarks)) return r;
-    return pocs_set_landmarks(c, v.data(), c->num_landmarks);
-  }
-  if (name == "setNumParticles") { if (int r = one_int(&n)) return r; return pocs_set_num_particles(c, n); }
-  if (name == "setInitialCovariance") { if (int r = numbers(9)) return r; return pocs_set_initial_covariance(c, v.data()); }
-  if (name == "setPathLength") { if (int r = one_int(&n)) return r; return pocs_set_path_length(c, (int)n); }
-  if (name == "setTrajectory") {
-    if (c->W < 1) return fail(c, POCS_E_ORDER, "setTrajectory before setPathLength");
-    if (int r = numbers((size_t)3 * c->W)) return r;
-    return pocs_set_trajectory(c, v.data(), c->W);
-  }
-  if (name == "setOdometry") {
-    if (c->W < 1) return fail(c, POCS_E_ORDER, "setOdometry before setPathLength");
-    if (int r = numbers((size_t)3 * (c->W - 1))) return r;
-    return pocs_set_odometry(c, v.data(), c->W - 1);
-  }
-  if (name == "setNumGaussians") { if (int r = one_int(&n)) return r; return pocs_set_num_gaussians(c, (int)n); }
-  if (name == "setNumGMMSamples") { if (int r = one_int(&n)) return r; return pocs_set_num_gmm_samples(c, n); }
-  if (name == "setSeed") {
-    while (*rest == ' ' || *rest == '\t') ++rest;
-    char* end = nullptr;
-    const unsigned long long s = strtoull(rest, &end, 0);
-    if (end == rest) return fail(c, POCS_E_ARG, "setSeed: integer expected");
-    return pocs_set_seed(c, (uint64_t)s);
-  }
-  if (name == "setFootprint") { if (int r = numbers(4)) return r; return pocs_set_footprint(c, v[0], v[1], v[2], v[3]); }
-  if (name == "addObstacle") {
-    if (int r = numbers(5)) return r;
-    std::vector<double> b = c->boxes;
-    b.insert(b.end(), v.begin(), v.end());
-    return pocs_set_obstacles(c, b.data(), (int)(b.size() / 5));
-  }
-  if (name == "clearObstacles") return pocs_set_obstacles(c, nullptr, 0);
-  if (name == "setBatch") { if (int r = one_int(&n)) return r; return pocs_set_batch(c, (int)n); }
-  if (name == "setRunAhead") { if (int r = one_int(&n)) return r; return pocs_set_option(c, POCS_OPT_RUN_AHEAD, n); }
-  if (name == "runSimulation" || name == "runGMMEstimation") {                 // :75-81, :66-72
-    double p = 0.0;
-    const int r = (name == "runSimulation") ? pocs_run_simulation(c, &p) : pocs_run_gmm_estimation(c, &p);
-    if (r) return r;
-    snprintf(buf, sizeof buf, "%.17g", p);
-    return put(c, out, cap, buf);
-  }
-  return fail(c, POCS_E_UNKNOWN_COMMAND, "unknown command '%s'", name.c_str());
+  return fail(c, POCS_E_UNKNOWN_COMMAND, "unknown command '%s'", p.name.c_str());
 }
 
 }  // extern "C"

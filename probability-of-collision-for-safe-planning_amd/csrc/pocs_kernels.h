@@ -13,16 +13,8 @@
 // co-resident blocks instead of one fat one: while one block is in its head or tail (parameter
 // staging, block reduction, the drain of its stores, ticket, mixture advance) the other block's waves
 // have the CU's issue slots.
-#ifdef POCS_GMM_BLOCK                      // sweeps: force one size for every K
-#define POCS_GMM_BLOCK_OF(K) (POCS_GMM_BLOCK)
-#else
 #define POCS_GMM_BLOCK_OF(K) 512
-#endif
-#ifdef POCS_GMM_BPC                        // sweeps
-#define POCS_GMM_BLOCKS_PER_CU POCS_GMM_BPC
-#else
 #define POCS_GMM_BLOCKS_PER_CU 2
-#endif
 #define POCS_NUM_CUS 256
 #define POCS_MAX_BLOCKS 2048
 // Task geometry of k_gmm_step.  A chunk = one iteration of a block = POCS_GMM_BLOCK_OF(K) pairs of samples.
@@ -31,9 +23,11 @@
 // chunks)), never on how many runs share the launch -- the moment sums are defined on the virtual slices
 // (pocs_kernels.hip, "summation tree"), which is what makes a run's result independent of the batch.
 // The launch's work = the flat list of units t = r * VS + j; block b takes units [b * upb, (b + 1) * upb).
-#ifndef POCS_GMM_MAX_VS            // (sweeps: a coarser cut changes the sums' last bits)
 #define POCS_GMM_MAX_VS 256
-#endif
+// Block size and slice count are part of the NUMERICS (the summation tree is defined on chunks of 512 pairs, 64-lane
+// waves and at most 256 virtual slices; oracle/pocs_oracle.c::tree_moments restates exactly these): a build with
+// other values would produce other last bits under the same version string.
+static_assert(POCS_GMM_BLOCK_OF(3) == 512 && POCS_GMM_MAX_VS == 256, "summation tree of numerics v8: 512-pair chunks, 256 virtual slices");
 #define POCS_GMM_SUB 32        // units whose wave sums a block holds in LDS at a time (64 runs x 256 slices / 512 blocks)
 #define POCS_UNIT_SUMS 10      // survivors + the nine sums
 #define POCS_FLUSH_ROWS 5      // flush_unit's transpose scratch per wave: 5 rows of 64 lane values,
@@ -92,6 +86,7 @@ struct pocs_gmm_launch {
   unsigned* sync;                // the call's synchronisation words, zeroed once per call:
                                  // [1] give-up code of a bounded wait (0 = none)
   unsigned* ticket;              // [nruns][W] arrival counters of the blocks of (run, waypoint); same zeroed block
+  unsigned* xwait;               // [nruns][W] sharded: how long the closer of (run, waypoint) waited for the world's rows (10 ns ticks); same block
   double* x; double* y; double* th;   // SoA sample buffers [nruns][sample_stride] (unused when !store)
   int16_t* flags;
   long long n_total;             // samples of the whole mixture (all shards): what the component counts add up to
@@ -101,6 +96,7 @@ struct pocs_gmm_launch {
   int nruns;
   int W;
   pocs_footprint fp;
+  double fp_rr, fp_phi;          // its bounding radius and corner angle atan2(hy, hx) (pocs_footprint_extent_pre)
   int M;
   int waypoint;
   int store;
@@ -112,10 +108,8 @@ struct pocs_gmm_launch {
   // launch geometry (above)
   long long chunks;              // of the shard
   int vs_shift;                  // VS = 1 << vs_shift virtual slices per run
-  int upb;                       // units per block (<= VS) of blocks [0, split)
-  int upb2, split;               // ... and of blocks [split, blocks): the second block of a CU -- the younger one, which the
-                                 // SIMDs' age-ordered arbitration leaves behind -- gets fewer (pocs_host.hip, gmm_geometry)
-  int blocks;                    // all of them
+  int upb;                       // units per block (<= VS)
+  int blocks;
   int run_lo, run_cnt;           // the runs of the batch this launch works on
 };
 #define POCS_SYNC_ABORT 1

@@ -80,7 +80,7 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
 }
 
 // Stage the log / sector tables (12 KB) into LDS.  The log table's 1/c entries are DOUBLED on the way in:
-// the device form of pocs_log_unit32 multiplies them with the mantissa in [1/2, 1) (pocs_math.h).
+// the device form of pocs_radius2_unit32 multiplies them with the mantissa in [1/2, 1) (pocs_math.h).
 __device__ __forceinline__ void stage_tables(const pocs_tables* __restrict__ g, pocs_tables* s_tab) {
   const double* src = reinterpret_cast<const double*>(g);
   double* dst = reinterpret_cast<double*>(s_tab);
@@ -145,14 +145,20 @@ __device__ __forceinline__ void acquire_agent() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the invalidate completes before the barrier releases the readers
 }
 
-#if defined(POCS_STAMPS)       // diagnostic build (tools/stamps.sh): where the blocks of a k_gmm_step launch spend their time
-__device__ unsigned long long g_stamps[24 * 256];            // a set per block (modulo 256): blocks in lockstep must not queue on one word
-#define POCS_STAMP_AT(i) (&g_stamps[(i) + 24 * (blockIdx.x & 255)])
-__device__ unsigned g_tn[512];                     // per block index: launches seen, and the time wave 0 spent in its units
-__device__ float g_t[512][2048];                   // in each of them (10 ns ticks): the spread WITHIN a launch
-#define POCS_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(POCS_STAMP_AT(i), n_ - last_); last_ = n_; } } while (0)
+// Diagnostic hooks (phase stamps, timing-only ablations of the sampling body): real only in a -DPOCS_TUNING build
+// (csrc/pocs_tuning.h, tools/ablate.sh); the shipped library sees the no-ops / pass-throughs below.
+#ifdef POCS_TUNING
+#include "pocs_tuning.h"
 #else
+#define POCS_STAMP_BEGIN() do { } while (0)
 #define POCS_STAMP(i) do { } while (0)
+#define POCS_STAMP_COUNT(i) do { } while (0)
+#define POCS_ADV_STAMP_BEGIN() do { } while (0)
+#define POCS_ADV_STAMP(i) do { } while (0)
+#define POCS_TUNE_NORMALS(...) __VA_ARGS__
+#define POCS_TUNE_COLLIDE(...) __VA_ARGS__
+#define POCS_TUNE_SKIP_MOMENTS false
+#define POCS_TUNE_MOMENTS_ALT() do { } while (0)
 #endif
 
 // LDS scratch of the mixture advance (doubles): state[w-1], moments, chain record, sensor, state[w], param[w];
@@ -280,35 +286,6 @@ __device__ __forceinline__ void advance_stage(const pocs_gmm_launch& a, int K, i
 // one wave, after advance_stage (+ barrier): one component per lane
 __device__ __forceinline__ void advance_components(const pocs_gmm_launch& a, int K, int w, int r, int lane, double* scratch) {
   const adv_ptrs p = advance_ptrs(a, K, w, r, scratch);
-#if defined(POCS_STAMPS) && defined(POCS_STAMPS_PIECES)
-  if (lane < K && w > 0) {
-    // the pieces of pocs_gmm_advance_component with the cycle counter read between them (alive components only)
-    const int k = lane;
-    const double* pv = p.l_prev + k * POCS_STATE_STRIDE;
-    const pocs_sensor* sen = reinterpret_cast<const pocs_sensor*>(p.l_sen);
-    unsigned long long c0 = __builtin_readcyclecounter(), c1;
-    double tm[3], tc[9], pm[3], pc[9], L[6];
-    double mom[POCS_NMOM];
-    for (int i = 0; i < POCS_NMOM; ++i) mom[i] = p.l_mom[k * POCS_NMOM + i];
-    double keepalive = pv[13];
-    asm volatile("" : "+v"(keepalive));
-#define CYC(i) do { c1 = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(POCS_STAMP_AT(i), c1 - c0); c0 = c1; } while (0)
-    CYC(16);
-    int ok = pocs_truncated_moments(mom, tm, tc);
-    asm volatile("" : "+v"(tc[8]), "+v"(tm[2]));
-    CYC(17);
-    pocs_ekf_predict(tm, tc, p.l_ch, p.l_ch + 3, pm, pc);
-    asm volatile("" : "+v"(pc[8]), "+v"(pm[2]));
-    CYC(18);
-    pocs_ekf_update(pm, pc, p.l_ch + POCS_CHAIN_Z, sen);
-    asm volatile("" : "+v"(pc[8]), "+v"(pm[2]));
-    CYC(19);
-    ok &= pocs_chol3_lower(pc, L);
-    asm volatile("" : "+v"(L[5]));
-    CYC(20);
-    (void)ok;
-  }
-#endif
   if (lane < K)
     pocs_gmm_advance_component(lane, p.l_prev, (w == 0) ? nullptr : p.l_mom, p.l_ch, p.l_ch + 3, p.l_ch + POCS_CHAIN_Z,
                                reinterpret_cast<const pocs_sensor*>(p.l_sen), p.l_next, p.l_par);
@@ -360,12 +337,7 @@ __device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, 
 __device__ __forceinline__ void advance_block(const pocs_gmm_launch& a, int K, int w, int r, double* adv, double* spec,
                                               bool mom_in_lds, int tid, int nthreads, const bool staged = false,
                                               const bool publish = true) {
-#if defined(POCS_STAMPS)
-  unsigned long long t_ = wall_clock64();
-#define POCS_ADV_STAMP(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(POCS_STAMP_AT(i), n_ - t_); t_ = n_; } } while (0)
-#else
-#define POCS_ADV_STAMP(i) do { } while (0)
-#endif
+  POCS_ADV_STAMP_BEGIN();
   if (!staged) {
     advance_stage(a, K, w, r, adv, mom_in_lds, tid, nthreads);
     __syncthreads();
@@ -441,6 +413,10 @@ __device__ __forceinline__ bool gmm_exchange_rows(const pocs_gmm_launch& a, cons
         break;
       }
     }
+    // how long this closer waited for rank `tid`'s row (10 ns ticks; its own row: no time): the longest of them is
+    // what the exchange cost this (run, waypoint) -- pocs_get_exchange_wait, for a scaling run that explains itself
+    const unsigned long long dt = wall_clock64() - t0;
+    __hip_atomic_fetch_max(&a.xwait[(size_t)r * a.W + w], (unsigned)(dt < 0xffffffffull ? dt : 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid < 64) {                                          // ONE wave, the one that polled: drop this XCD's stale lines
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // system scope
@@ -562,8 +538,8 @@ __device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, T
   xlo -= pad; xhi += pad; ylo -= pad; yhi += pad;
   tlo -= 1e-9 * (1.0 + fabs(tlo)); thi += 1e-9 * (1.0 + fabs(thi));
   const double HALF_PI = 1.57079632679489661923;
-  const double ext_x = pocs_footprint_extent(fp.hx, fp.hy, tlo, thi);
-  const double ext_y = pocs_footprint_extent(fp.hx, fp.hy, tlo - HALF_PI, thi - HALF_PI);
+  const double ext_x = pocs_footprint_extent_pre(fp.hx, fp.hy, a.fp_rr, a.fp_phi, tlo, thi);
+  const double ext_y = pocs_footprint_extent_pre(fp.hx, fp.hy, a.fp_rr, a.fp_phi, tlo - HALF_PI, thi - HALF_PI);
   bool keep = false;
   double bx = 0.0, by = 0.0;
   if (lane < M) {
@@ -616,7 +592,6 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
   const uint64_t pair0 = (uint64_t)(a.first >> 1);
   const double first_d = (double)a.first;
   const int wave_first = 128 * wave;                // the wave's first sample within a chunk
-#if !defined(POCS_NO_PRIO_ROTATION)
   // The (up to) four waves of a SIMD -- two of this block, two of the co-resident one -- are arbitrated
   // by priority, then AGE: left alone, the oldest wave of a SIMD runs ~1.7 x faster than the youngest for
   // the whole launch.  Rotating the priority with the iteration gives every wave the same share.
@@ -624,10 +599,6 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
   // one.  The second block of a CU is (observed, speed only) the one dispatched 256 blocks later.
   const int prio_slot = (TB >= 512 ? (wave >> 2) : 0) + (TB >= 512 ? 2 : 1) * (int)((blockIdx.x >> 8) & 3u);
   int prio_it = prio_slot;
-#if defined(POCS_PRIO_TIME_SHIFT)
-  unsigned prio_clk = (unsigned)(wall_clock64() >> POCS_PRIO_TIME_SHIFT);
-#endif
-#endif
   // per run (wave-uniform; reloaded when the block's range crosses into its second run)
   int rb = -1, nkeep = 0, kcur = 0, kw = 0;
   const double* s_par = nullptr;
@@ -637,12 +608,8 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
   double *xr = nullptr, *yr = nullptr, *tr = nullptr;
   int16_t* fr = nullptr;
   int seg_end = 0;                                  // local sample index up to which (exclusive) the samples belong to component kw and exist
-#if !defined(POCS_NO_VCONST)
-  POCS_VCONST(vc_);                                 // three polynomial constants held in vector registers (pocs_math.h)
+  POCS_VCONST(vc_);                                 // polynomial constants held in vector registers (pocs_math.h)
   const pocs_vconst* const vc = &vc_;
-#else
-  const pocs_vconst* const vc = nullptr;
-#endif
 
   // ONE iteration = 2 * TB samples, one pair per thread.  WHOLE (compile time): the wave's 128 samples lie
   // inside component block kw and inside the shard -- every lane live, both samples of its pair exist,
@@ -650,36 +617,16 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
   // wave, the shard's last chunk), every decision per lane.  Same arithmetic per sample either way.
   auto iteration = [&](auto whole_tag, const int base, const int tl, bool& first) __attribute__((always_inline)) {
     constexpr bool WHOLE = decltype(whole_tag)::value;
-#if !defined(POCS_NO_PRIO_ROTATION)
-#if defined(POCS_PRIO_TIME_SHIFT)
-    prio_it = (int)prio_clk + prio_slot;           // by TIME: every wave of the SIMD holds every level for the same time, whatever its pace
-    prio_clk = (unsigned)(wall_clock64() >> POCS_PRIO_TIME_SHIFT);      // (for the next iteration: the read is not waited for here)
-#endif
     switch (prio_it++ & 3) {                       // s_setprio takes an immediate
       case 0: __builtin_amdgcn_s_setprio(0); break;
       case 1: __builtin_amdgcn_s_setprio(1); break;
       case 2: __builtin_amdgcn_s_setprio(2); break;
       default: __builtin_amdgcn_s_setprio(3); break;
     }
-#endif
     const int lp = base + tid;
     const bool live = WHOLE || lp < npairs;        // a lane past the end computes, masked
     double zz[2][3];
     uint32_t spare[2];
-#if defined(POCS_ABLATE_RNG)          // timing-only builds (tools/ablate.sh): outputs are wrong
-    for (int h = 0; h < 2; ++h) { zz[h][0] = (double)(lp & 7) * 0.1; zz[h][1] = (double)(lp & 3) * 0.1; zz[h][2] = 0.05; spare[h] = (uint32_t)lp * 2654435761u; }
-#elif defined(POCS_ABLATE_PHILOX)      // Box-Muller kept, its words from a three-instruction hash: what Philox costs in situ
-    { const uint32_t q = (uint32_t)(pair0 + lp) * 2654435761u ^ (uint32_t)seed ^ ((uint32_t)w << 20);
-      const uint32_t a0 = q * 0x9E3779B1u, a1 = (q ^ 0x85EBCA6Bu) * 0xC2B2AE35u, a2 = (q + 0x27D4EB2Fu) * 0x165667B1u;
-      pocs_normal_pair_w2(a0, a1, s_tab, &zz[0][0], &zz[0][1]);
-      pocs_normal_pair_w2(a2, a0 ^ a1, s_tab, &zz[0][2], &zz[1][0]);
-      pocs_normal_pair_w2(a1 ^ a2, a0 + a2, s_tab, &zz[1][1], &zz[1][2]);
-      spare[0] = a0; spare[1] = a1; }
-#elif defined(POCS_ABLATE_BOXMULLER)
-    { const pocs_u32x4 A = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 0u), B = pocs_draw(seed, pair0 + lp, (uint32_t)w, POCS_STREAM_GMM, 1u);
-      zz[0][0] = (double)A.x * 0x1p-32; zz[0][1] = (double)A.y * 0x1p-32; zz[0][2] = (double)A.z * 0x1p-32; spare[0] = B.z;
-      zz[1][0] = (double)A.w * 0x1p-32; zz[1][1] = (double)B.x * 0x1p-32; zz[1][2] = (double)B.y * 0x1p-32; spare[1] = B.w; }
-#else
     // The seed is made opaque once per iteration: otherwise the compiler hoists all 20 Philox round
     // keys (seed + r * Weyl constants) out of the loop and pins 20 SGPRs of a register file that is
     // already spilling; recomputing them costs 2 scalar adds per round.
@@ -687,8 +634,7 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(seed_it));
 #endif
-    pocs_normal3_pair(seed_it, pair0 + (uint64_t)(unsigned)lp, (uint32_t)w, POCS_STREAM_GMM, s_tab, zz[0], zz[1], &spare[0], &spare[1], vc);
-#endif
+    POCS_TUNE_NORMALS(pocs_normal3_pair(seed_it, pair0 + (uint64_t)(unsigned)lp, (uint32_t)w, POCS_STREAM_GMM, s_tab, zz[0], zz[1], &spare[0], &spare[1], vc));
     const int i0 = 2 * lp;
     const bool two = WHOLE || (live && (i0 + 1) < count);  // false only for the last sample of an odd shard
     double xs[2], ys[2], ts[2];
@@ -712,14 +658,8 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
       ts[h] = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
       ks[h] = k;
     }
-#if defined(POCS_ABLATE_COLLIDE)
-    hits[0] = xs[0] > ts[0]; hits[1] = xs[1] > ts[1];
-#else
-    pocs_pair_collides(xs, ys, ts, &fp, s_keep, nkeep, s_tab, vc, hits);
-#endif
-#if defined(POCS_ABLATE_MOMENTS)
-    acc[1] += xs[0] + ys[0] + ts[0] + xs[1]; nfree += (hits[0] || (two && ks[1] == 0)) ? 0 : 1;
-#else
+    POCS_TUNE_COLLIDE(pocs_pair_collides(xs, ys, ts, &fp, s_keep, nkeep, s_tab, vc, hits));
+    if constexpr (POCS_TUNE_SKIP_MOMENTS) { POCS_TUNE_MOMENTS_ALT(); } else {
     // T1 sums over the collision-free samples of the component being accumulated:
     //   (x, y, t, x x, x y, x t, y y, y t, t t) with the products inside the fma; survivors by population count.
     if (WHOLE) {
@@ -759,7 +699,7 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
         }
       }
     }
-#endif
+    }
     if (STORE && live) {
       // Both poses of the pair leave together.  For the last sample of an odd shard the second slot is
       // the pair's unused twin: it lands in the padding element of the run's slice (sample_stride >=
@@ -833,9 +773,7 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
         base += TB;
       }
     }
-#if !defined(POCS_NO_PRIO_ROTATION)
     __builtin_amdgcn_s_setprio(3);                   // flushes run at the top priority: other waves will wait for them
-#endif
     flush_unit(sm, wave, lane, rb, tl, kcur, first, acc, nfree);      // the unit's last component
   }
 }
@@ -877,27 +815,36 @@ __device__ __forceinline__ void gmm_emit_rows(const pocs_gmm_launch& a, gmm_smem
 // this shard's samples: nColl_k = n_k - nFree_k, with [cum_{k-1}, cum_k) the component's global sample
 // range (par[k][9], cum_{K-1} = n_total).  Result: tot[c], and moments[w][r][c] in global memory (it
 // leaves the launch at the kernel boundary).
-template <int K>
+template <int K, int NT>
 __device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const int w, const int r, const double* s_par,
-                                               double* stage, double* tot, const int tid, const int nthreads,
+                                               double* stage, double* tot, const int tid,
                                                const double* rows, const bool store) {
-  constexpr int NC = K * POCS_NMOM, G = 16;
+  constexpr int NC = K * POCS_NMOM, G = 16, ITEMS = G * NC, RPI = POCS_GMM_MAX_VS / G, nthreads = NT;
   const int S = 1 << a.vs_shift;
   const double* src = rows + (size_t)r * S * NC;
-  for (int i = tid; i < G * NC; i += nthreads) {
-    const int g = i / NC, c = i - g * NC;
-    // the item's (up to) sixteen rows g, g + 16, ... are all requested before the first is waited for -- ONE
-    // memory round trip for the run's 256 rows -- and added in row order
-    double v[POCS_GMM_MAX_VS / G];
+  // An item's (up to) sixteen rows g, g + 16, ... are all requested before the first is waited for, and so are the
+  // rows of the thread's NEXT item where there are more items than threads (K = 3: 528 items on 512 threads --
+  // taken one after the other, sixteen threads cost the whole block a second memory round trip): two items per
+  // batch, ONE round trip per batch for the run's 256 rows.  Added in row order.
+  for (int i0 = tid; i0 < ITEMS; i0 += 2 * NT) {
+    double v[2][RPI];
 #pragma unroll
-    for (int u = 0; u < POCS_GMM_MAX_VS / G; ++u) {
-      const int q = g + u * G;
-      v[u] = q < S ? load_wt(&src[(size_t)q * NC + c]) : 0.0;
+    for (int t = 0; t < 2; ++t) {
+      const int i = i0 + t * NT, g = i / NC, c = i - g * NC;
+#pragma unroll
+      for (int u = 0; u < RPI; ++u) {
+        const int q = g + u * G;
+        v[t][u] = (i < ITEMS && q < S) ? load_wt(&src[(size_t)q * NC + c]) : 0.0;
+      }
     }
-    double t = 0.0;
 #pragma unroll
-    for (int u = 0; u < POCS_GMM_MAX_VS / G; ++u) if (g + u * G < S) t += v[u];
-    stage[i] = t;
+    for (int t = 0; t < 2; ++t) {
+      const int i = i0 + t * NT, g = i / NC;
+      double sum = 0.0;
+#pragma unroll
+      for (int u = 0; u < RPI; ++u) if (g + u * G < S) sum += v[t][u];
+      if (i < ITEMS) stage[i] = sum;
+    }
   }
   __syncthreads();
   for (int c = tid; c < NC; c += nthreads) {
@@ -945,21 +892,16 @@ __device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const i
 template <int K, bool STORE, int TB, bool LONE>
 __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_step(pocs_gmm_launch a) {
   typedef gmm_smem<K, TB> smem_t;
-  constexpr int NC = smem_t::NC, SUB = smem_t::SUB, NW = smem_t::NW;
+  constexpr int SUB = smem_t::SUB, NW = smem_t::NW;
   __shared__ smem_t sm;
   const int tid = threadIdx.x;
   const int w = a.waypoint;
-  const int VS = 1 << a.vs_shift;
   const int t_lo = a.run_lo << a.vs_shift, t_hi = (a.run_lo + a.run_cnt) << a.vs_shift;    // this launch's units
   const int bx = (int)blockIdx.x;
-  const int my_upb = bx < a.split ? a.upb : a.upb2;
-  const int t0 = t_lo + (bx < a.split ? bx * a.upb : a.split * a.upb + (bx - a.split) * a.upb2);
-  const int t1 = (t0 + my_upb < t_hi) ? t0 + my_upb : t_hi;
+  const int t0 = t_lo + bx * a.upb;
+  const int t1 = (t0 + a.upb < t_hi) ? t0 + a.upb : t_hi;
   const int r0 = t0 >> a.vs_shift, r1 = (t1 - 1) >> a.vs_shift;       // the block's first and last run (r1 <= r0 + 1)
-#if defined(POCS_STAMPS)
-  unsigned long long last_ = wall_clock64();
-  if (tid == 0) atomicAdd(POCS_STAMP_AT(15), 1ull);
-#endif
+  POCS_STAMP_BEGIN();
   stage_tables(a.tables, &sm.tab);
   if (LONE && w > 0) {
     // close waypoint w - 1 and advance to w, here (r0 is the call's one run)
@@ -970,14 +912,12 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
     for (int j = tid; j < 2 * NW * K; j += TB) (&sm.xj[0][0][0])[j] = -1;
     if (tid == 0) sm.seed[0] = a.hdr[r0].seed;
     double* const l_mom = advance_ptrs(a, K, w, r0, sm.adv()).l_mom;
-    gmm_close_sums<K>(a, w - 1, r0, sm.par[1], sm.stage(), l_mom, tid, TB, a.partial_prev, out);   // ... with the rows'
+    gmm_close_sums<K, TB>(a, w - 1, r0, sm.par[1], sm.stage(), l_mom, tid, a.partial_prev, out);   // ... with the rows'
     POCS_STAMP(5);
     advance_block(a, K, w, r0, sm.adv(), sm.spec(), true, tid, TB, true, out);
     __syncthreads();
     POCS_STAMP(6);
-#if defined(POCS_STAMPS)
-    if (tid == 0) atomicAdd(POCS_STAMP_AT(14), 1ull);
-#endif
+    POCS_STAMP_COUNT(14);
     const double* const l_par = advance_ptrs(a, K, w, r0, sm.adv()).l_par;
     for (int j = tid; j < PS; j += TB) sm.par[0][j] = l_par[j];
     for (int j = tid; j < a.M * POCS_OBS_STRIDE; j += TB) sm.obs()[j] = a.env->obs[j];     // (the staging rows are done with)
@@ -997,22 +937,8 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   for (int ta = t0; ta < t1; ta += SUB) {
     const int tb = (ta + SUB < t1) ? ta + SUB : t1;
     gmm_units<K, STORE, TB>(a, sm, w, r0, ta, tb);
-#if defined(POCS_STAMPS)
-    __shared__ unsigned long long s_wend[NW];
-    if ((tid & 63) == 0) s_wend[tid >> 6] = wall_clock64();
-    const unsigned long long units_ = wall_clock64() - last_;
-#endif
     POCS_STAMP(1);
     __syncthreads();
-#if defined(POCS_STAMPS)
-    if (tid == 0) {                                  // how far apart the block's waves finish, and the blocks' spread (sum of squares)
-      unsigned long long lo = s_wend[0], hi = s_wend[0];
-      for (int u = 1; u < NW; ++u) { lo = s_wend[u] < lo ? s_wend[u] : lo; hi = s_wend[u] > hi ? s_wend[u] : hi; }
-      atomicAdd(POCS_STAMP_AT(21), hi - lo);
-      atomicAdd(POCS_STAMP_AT(22), units_ * units_);
-      if (blockIdx.x < 512) { const unsigned n = g_tn[blockIdx.x]++; if (n < 2048) g_t[blockIdx.x][n] = (float)units_; }
-    }
-#endif
     POCS_STAMP(2);
     gmm_emit_rows(a, sm, r0, ta, tb);
     if (tb < t1) {                                   // more units to come (only launches of > 64 runs): the slots start over
@@ -1027,8 +953,7 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   POCS_STAMP(3);
   if (tid <= r1 - r0) {                              // one ticket per run touched: the blocks whose range meets [r VS, (r + 1) VS)
     const int r = r0 + tid;
-    auto block_of = [&](const int t_rel) { return t_rel < a.split * a.upb ? t_rel / a.upb : a.split + (t_rel - a.split * a.upb) / a.upb2; };
-    const int b_first = block_of((r << a.vs_shift) - t_lo), b_last_raw = block_of((((r + 1) << a.vs_shift) - 1) - t_lo);
+    const int b_first = ((r << a.vs_shift) - t_lo) / a.upb, b_last_raw = ((((r + 1) << a.vs_shift) - 1) - t_lo) / a.upb;
     const int b_last = b_last_raw < (int)gridDim.x - 1 ? b_last_raw : (int)gridDim.x - 1;
     const unsigned t = __hip_atomic_fetch_add(&a.ticket[(size_t)r * a.W + w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sm.last[tid] = (t == (unsigned)(b_last - b_first)) ? 1 : 0;
@@ -1045,7 +970,7 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
     if (tid == 0) acquire_agent();
     __syncthreads();
     double* const l_mom = advance_ptrs(a, K, w + 1, r, sm.adv()).l_mom;
-    gmm_close_sums<K>(a, w, r, sm.par[rb], sm.stage(), l_mom, tid, TB, a.partial, true);
+    gmm_close_sums<K, TB>(a, w, r, sm.par[rb], sm.stage(), l_mom, tid, a.partial, true);
     POCS_STAMP(5);
     if (a.exchange_in_tail) {
       // sharded: the run's closer is also its messenger -- this shard's moments go to every rank, the world's
@@ -1057,9 +982,7 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
     if (a.advance_in_tail) advance_block(a, K, w + 1, r, sm.adv(), sm.spec(), true, tid, TB);     // starts with a barrier after staging
     __syncthreads();
     POCS_STAMP(6);
-#if defined(POCS_STAMPS)
-    if (tid == 0) atomicAdd(POCS_STAMP_AT(14), 1ull);
-#endif
+    POCS_STAMP_COUNT(14);
     return true;
   };
   const int last0 = __builtin_amdgcn_readfirstlane(sm.last[0]), last1 = __builtin_amdgcn_readfirstlane(sm.last[1]);
@@ -1076,7 +999,7 @@ __global__ __launch_bounds__(256) void k_gmm_close(pocs_gmm_launch a) {
   __shared__ double s_tot[NC];
   const int w = a.waypoint, r = a.run_lo;
   for (int j = threadIdx.x; j < PS; j += 256) s_par[j] = a.param[((size_t)r * a.W + w) * PS + j];
-  gmm_close_sums<K>(a, w, r, s_par, s_stage, s_tot, threadIdx.x, 256, a.partial, true);    // (first barrier: s_par is in)
+  gmm_close_sums<K, 256>(a, w, r, s_par, s_stage, s_tot, threadIdx.x, a.partial, true);    // (first barrier: s_par is in)
 }
 
 // MC kernels: blockIdx.y = run of the batch (its own seed, its own noisy controls, its own slice
@@ -1230,56 +1153,9 @@ hipError_t launch_gmm_close_k(const pocs_gmm_launch& a, hipStream_t s) {
 
 }  // namespace
 
-#if defined(POCS_STAMPS)
-extern "C" void pocs_stamps_report() {
-  static unsigned long long all[24 * 256];
-  unsigned long long h[24] = {0};
-  if (hipMemcpyFromSymbol(all, HIP_SYMBOL(g_stamps), sizeof all) != hipSuccess) return;
-  for (int b = 0; b < 256; ++b) for (int i = 0; i < 24; ++i) h[i] += all[24 * b + i];
-  if (h[15] == 0) return;
-  const double nb = (double)h[15], nc = (double)(h[14] ? h[14] : 1);
-  fprintf(stderr, "[stamps] %.0f blocks, %.0f closers; per block (us): head %.2f | units %.2f | -> barrier %.2f | rows + drain + barrier %.2f | "
-          "ticket + barrier %.2f ; per closer: close_sums %.2f | advance %.2f (staging %.2f, components (wave 0) %.2f, -> the counts lane %.2f, normalise + publish + drain %.2f)\n",
-          nb, nc, 0.01 * h[0] / nb, 0.01 * h[1] / nb, 0.01 * h[2] / nb, 0.01 * h[3] / nb, 0.01 * h[4] / nb, 0.01 * h[5] / nc, 0.01 * h[6] / nc,
-          0.01 * h[8] / nc, 0.01 * h[9] / nc, 0.01 * h[10] / nc, 0.01 * h[11] / nc);
-  fprintf(stderr, "[stamps] a block's waves finish %.2f us apart (first to last); units of wave 0: mean %.2f, sd over blocks %.2f us\n",
-          0.01 * h[21] / nb, 0.01 * h[1] / nb, 0.01 * sqrt(fmax(0.0, (double)h[22] / nb - ((double)h[1] / nb) * ((double)h[1] / nb))));
-  {
-    static unsigned tn[512];
-    static float tt[512][2048];
-    if (hipMemcpyFromSymbol(tn, HIP_SYMBOL(g_tn), sizeof tn) == hipSuccess && hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_t), sizeof tt) == hipSuccess) {
-      int nb_ = 0;
-      while (nb_ < 512 && tn[nb_] == tn[0] && tn[0] > 0) ++nb_;
-      const unsigned nl = tn[0] < 2048 ? tn[0] : 2048;
-      double ssd = 0, srange = 0, shalf = 0;
-      for (unsigned n = 0; n < nl; ++n) {
-        double m = 0, q = 0, lo = 1e30, hi = 0, ma = 0, mb = 0;
-        for (int b = 0; b < nb_; ++b) { const double v = tt[b][n]; m += v; q += v * v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; (b < nb_ / 2 ? ma : mb) += v; }
-        m /= nb_; ssd += sqrt(fmax(0.0, q / nb_ - m * m)); srange += hi - lo; shalf += (mb - ma) / (nb_ / 2);
-      }
-      if (nl && nb_ > 1) {
-        // is a block index slow in EVERY launch?  per-block means over the launches, by XCD (b mod 8) and by residency (b / 256)
-        double bm[512], all = 0, byx[8] = {0}, sdm = 0;
-        for (int b = 0; b < nb_; ++b) { double m = 0; for (unsigned n = 0; n < nl; ++n) m += tt[b][n]; bm[b] = m / nl; all += bm[b]; byx[b & 7] += bm[b]; }
-        all /= nb_;
-        for (int b = 0; b < nb_; ++b) sdm += (bm[b] - all) * (bm[b] - all);
-        fprintf(stderr, "[stamps] per-block means over the launches: sd %.2f us; by b mod 8 (us):", 0.01 * sqrt(sdm / nb_));
-        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", 0.01 * byx[x] / (nb_ / 8));
-        double lo = 1e30, hi = 0; int ilo = 0, ihi = 0;
-        for (int b = 0; b < nb_; ++b) { if (bm[b] < lo) { lo = bm[b]; ilo = b; } if (bm[b] > hi) { hi = bm[b]; ihi = b; } }
-        fprintf(stderr, "; fastest block %d %.1f, slowest %d %.1f\n", ilo, 0.01 * lo, ihi, 0.01 * hi);
-      }
-      if (nl && nb_ > 1) fprintf(stderr, "[stamps] WITHIN a launch (%d blocks, %u launches): sd of the blocks' unit times %.2f us, slowest - fastest %.2f us, second half of the grid - first half %.2f us\n",
-                                 nb_, nl, 0.01 * ssd / nl, 0.01 * srange / nl, 0.01 * shalf / nl);
-    }
-    for (auto& v : tn) v = 0;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tn), tn, sizeof tn);
-  }
-  fprintf(stderr, "[stamps] a component done a second time, in pieces (cycles per closer): LDS reads %.0f | truncated moments %.0f | predict %.0f | update %.0f | chol %.0f\n",
-          (double)h[16] / nc, (double)h[17] / nc, (double)h[18] / nc, (double)h[19] / nc, (double)h[20] / nc);
-  for (auto& v : all) v = 0;
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), all, sizeof all);
-}
+#ifdef POCS_TUNING
+#define POCS_TUNING_REPORT
+#include "pocs_tuning.h"
 #endif
 
 hipError_t pocs_launch_gmm_close(int K, const pocs_gmm_launch& a, hipStream_t s) {

@@ -6,7 +6,7 @@
 //     is an explicit fma();
 //   * only +, -, *, /, sqrt, fma, rint and integer ops are used (all correctly rounded on
 //     both sides), never a vendor libm transcendental.
-// The spec ("POCS numerics v6") is written out in DESIGN.md section 4; the CPU oracle under
+// The spec ("POCS numerics v8") is written out in DESIGN.md section 4; the CPU oracle under
 // oracle/ holds an independent plain-C restatement of the same spec and is never linked here.
 //
 // What this replaces in the reference: Armadillo's RNG + mvnrnd (GM_Model.h:83-116,
@@ -179,30 +179,31 @@ POCS_HD void pocs_normal_pair(uint32_t w0, uint32_t w1, uint32_t w2, double* n0,
 }
 
 // ----------------------------------------------------------------------------------------
-// Table-driven forms used on the hot path (mixture samples, footprint heading): the same
-// functions to ~1 ulp with less than half the instructions.  The 12 KB of tables are built once
-// on the host FROM THE FUNCTIONS ABOVE (so product and oracle, whose functions agree bit for
-// bit, build identical tables) and staged in LDS by the kernels.
-//   lg[i] = {invc_i, logc_i}, c_i = 1 + (i + 1/2)/512:  invc_i = 1/c_i rounded, logc_i = -log(invc_i)
-//   sc[s] = {cos, sin} of the centre of sector s of 256: angle 2 pi (s + 1/2)/256
-// (12 KB; v4 had 128 / 64 entries and two more polynomial terms in each of log, sin and cos)
+// Table-driven forms used on the hot path (mixture samples, footprint heading): less than half the
+// instructions of the polynomial forms above.  The 12 KB of tables are built once on the host FROM THE
+// FUNCTIONS ABOVE (so product and oracle, whose functions agree bit for bit, build identical tables) and
+// staged in LDS by the kernels.  Numerics v8:
+//   lg[i] = {invc_i, 2 log(invc_i)},  c_i = 1 + (i + 1/2)/512,  invc_i = 1/c_i rounded
+//   sc[s] = {cos, sin} of 2 pi s / 256: the sector BOUNDARIES (v7 held the centres: the heading then paid
+//           half a sector's shift per evaluation; for the Box-Muller angle a fixed rotation is no change of law)
 // ----------------------------------------------------------------------------------------
 struct pocs_tables {
   double lg[512][2];
   double sc[256][2];
 };
 
-// The first Horner step of each of the three polynomials below multiplies by one literal and adds another; a
+// The first Horner step of the sine and cosine polynomials below multiplies by one literal and adds another; a
 // gfx950 VALU instruction reads at most one literal / scalar operand, so one of the two needs a register and
-// the compiler materialises it with a v_mov_b64 EVERY time (13 per pair of samples).  The hot kernel keeps
-// the three addends in vector registers for the length of its loop instead (POCS_VCONST pins them there);
-// same values, same operations.  Everyone else passes nullptr and gets the literals.
-struct pocs_vconst { double log_c4, sin_c3, cos_c4; };    // -1/4, -1/6, 1/24
+// the compiler materialises it with a v_mov_b64 EVERY time.  The hot kernel keeps the two addends in vector
+// registers for the length of its loop instead (POCS_VCONST pins them there); same values, same operations.
+// Everyone else passes nullptr and gets the literals.  (The radius polynomial of v8 needs none: its addends
+// are inline constants of the instruction set.)
+struct pocs_vconst { double sin_c3, cos_c4; };    // -1/6, 1/24
 #if defined(__HIP_DEVICE_COMPILE__)
-#define POCS_VCONST(name) pocs_vconst name = {-1.0 / 4.0, -1.0 / 6.0, 1.0 / 24.0}; \
-  asm volatile("" : "+v"(name.log_c4), "+v"(name.sin_c3), "+v"(name.cos_c4))
+#define POCS_VCONST(name) pocs_vconst name = {-1.0 / 6.0, 1.0 / 24.0}; \
+  asm volatile("" : "+v"(name.sin_c3), "+v"(name.cos_c4))
 #else
-#define POCS_VCONST(name) pocs_vconst name = {-1.0 / 4.0, -1.0 / 6.0, 1.0 / 24.0}
+#define POCS_VCONST(name) pocs_vconst name = {-1.0 / 6.0, 1.0 / 24.0}
 #endif
 
 POCS_HD void pocs_tables_init(pocs_tables* T) {
@@ -210,21 +211,25 @@ POCS_HD void pocs_tables_init(pocs_tables* T) {
     const double c = 1.0 + ((double)i + 0.5) * 0x1p-9;
     const double invc = 1.0 / c;
     T->lg[i][0] = invc;
-    T->lg[i][1] = -pocs_log(invc);
+    T->lg[i][1] = 2.0 * pocs_log(invc);
   }
   for (int s = 0; s < 256; ++s) {
     double sn, cs;
-    pocs_sincos_2pi_u32(((uint32_t)s << 24) + (1u << 23), &sn, &cs);
+    pocs_sincos_2pi_u32((uint32_t)s << 24, &sn, &cs);
     T->sc[s][0] = cs;
     T->sc[s][1] = sn;
   }
 }
 
-// log((w + 1) * 2^-32) for a 32-bit word w, i.e. log of a uniform on (0, 1] with 2^32 levels:
-// m = w + 1 = 2^e t, t in [1,2); i = top 9 mantissa bits; r = t*invc_i - 1 (one fma,
-// |r| < 2^-9.9); log = (e-32) ln2 + logc_i + log1p(r), log1p by its degree-5 Taylor polynomial
-// (truncation < 2^-62 absolute).
-POCS_HD double pocs_log_unit32(uint32_t w, const pocs_tables* T, const pocs_vconst* V = nullptr) {
+// The squared Box-Muller radius -2 log((w + 1) 2^-32) of a 32-bit word w, i.e. of a uniform on (0, 1] with
+// 2^32 levels, in ONE pass (v7 took the logarithm, then doubled it):
+//   m = w + 1 = 2^e t, t in [1, 2); i = top 9 mantissa bits; r = t invc_i - 1 (one fma, |r| <= 2^-10);
+//   -2 log t = 2 log(invc_i) - 2 log1p(r),   -2 log1p(r) = r (-2 + r (1 + r (-2/3 + r/2)))   (truncation < 4e-16);
+//   result = fma(e - 32, -2 ln 2, 2 log(invc_i) - 2 log1p(r)):
+// one product with ln 2, not a high and a low one -- the result is rounded once at its own magnitude, and where it
+// cancels (u near 1: e = 31, the table entry near -2 ln 2) a few 1e-16 of absolute error are six orders below the
+// 4.7e-10 between two neighbouring levels of the word.  Absolute error <= 1e-15 over all 2^32 words (CPU tests).
+POCS_HD double pocs_radius2_unit32(uint32_t w, const pocs_tables* T) {
   union { double d; uint64_t u; } b; b.d = (double)w + 1.0;      // exact: m <= 2^32
 #if defined(__HIP_DEVICE_COMPILE__)
   // The same quantities with fewer instructions.  m = 2^e t = 2^(e+1) mant with mant = t / 2 in [1/2, 1): the
@@ -236,21 +241,20 @@ POCS_HD double pocs_log_unit32(uint32_t w, const pocs_tables* T, const pocs_vcon
   const unsigned off = ((unsigned)(b.u >> 32) >> 7) & 0x1ff0u;    // 16 i
   const double* ent = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&T->lg[0][0]) + off);
   const double r = fma(mant, ent[0], -1.0);
-  const double logc = ent[1];
+  const double l2c = ent[1];
   const double dk = (double)(e1 - 33);
 #else
   const int e = (int)(b.u >> 52) - 1023;
   const int i = (int)(b.u >> 43) & 511;
   b.u = (b.u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;   // t
   const double r = fma(b.d, T->lg[i][0], -1.0);
-  const double logc = T->lg[i][1];
+  const double l2c = T->lg[i][1];
   const double dk = (double)(e - 32);
 #endif
-  double p = fma(r, 1.0 / 5.0, V ? V->log_c4 : -1.0 / 4.0);
-  p = fma(r, p, 1.0 / 3.0);
-  p = fma(r, p, -0.5);
-  p = fma(r * r, p, r);                                           // log1p(r)
-  return fma(dk, 6.93147180369123816490e-01, logc) + fma(dk, 1.90821492927058770002e-10, p);
+  double p = fma(r, 0.5, -2.0 / 3.0);
+  p = fma(r, p, 1.0);
+  p = fma(r, p, -2.0);
+  return fma(dk, -1.386294361119890572454e+00, l2c + r * p);      // -2 ln 2
 }
 
 // sin / cos of a small angle |d| <= pi/256 (Taylor to d^5 / d^6: truncation < 1e-17)
@@ -263,7 +267,9 @@ POCS_HD void pocs_sincos_small(double d, double* sd, double* cd, const pocs_vcon
   *cd = fma(z, pc, 1.0);
 }
 
-// sin and cos of 2 pi w 2^-32: sector = top 8 bits, d = offset from the sector centre.
+// sin and cos of the Box-Muller angle of a 32-bit word: sector = top 8 bits, d = the low 24 bits as an offset in
+// [-pi/256, pi/256) from that sector's table entry, i.e. the angle 2 pi (w - 2^23) 2^-32 -- uniform on the
+// circle with 2^32 levels like 2 pi w 2^-32 itself.
 POCS_HD void pocs_sincos_2pi_u32_tab(uint32_t w, const pocs_tables* T, double* sn, double* cs, const pocs_vconst* V = nullptr) {
   const int s = (int)(w >> 24);
   const int f = (int)(w & 0x00ffffffu) - (1 << 23);                       // [-2^23, 2^23)
@@ -275,18 +281,17 @@ POCS_HD void pocs_sincos_2pi_u32_tab(uint32_t w, const pocs_tables* T, double* s
   *cs = fma(C, cd, -(S * sd));
 }
 
-// sin and cos of an arbitrary angle |x| < 2^18 by the same sectors: n = floor(x * 256/(2 pi)),
-// d = x - n * (2 pi / 256) in three Cody-Waite steps (33 + 33 + 53 bit split of pi/128), then the
-// offset from the centre of sector n mod 256.
+// sin and cos of an arbitrary angle |x| < 2^18 by the same sectors: n = rint(x * 256/(2 pi)), d = x - n (2 pi / 256)
+// in two Cody-Waite steps -- pi/128 = P1 + P2, P1 its first 34 bits (n P1 is exact), P2 the rest rounded to double
+// (what is left of pi/128 after P2, 5.5e-29, times n < 2^24 is far below an ulp of d) -- so |d| <= pi/256 from
+// the table entry of sector n mod 256.  (v7: floor, three steps and half a sector's shift.)
 POCS_HD void pocs_sincos_tab(double x, const pocs_tables* T, double* sn, double* cs, const pocs_vconst* V = nullptr) {
-  const double fn = floor(x * 4.07436654315252084757e+01);
+  const double fn = rint(x * 4.07436654315252084757e+01);
   const int n = (int)fn;
-  double d = fma(-fn, 2.45436926052207127213e-02, x);    // pi/128, first 33 bits (fn * it is exact)
-  d = fma(-fn, 9.49546954109994683843e-13, d);           // next 33 bits
-  d = fma(-fn, 3.15979101374367286178e-23, d);           // tail
-  // sector centres sit at (s + 1/2) * pi/128: shift by half a sector
+  double d = fma(-fn, 2.45436926052207127213e-02, x);    // P1
+  d = fma(-fn, 9.495469541415925389561e-13, d);          // P2
   double sd, cd;
-  pocs_sincos_small(d - 1.22718463030851293594e-02, &sd, &cd, V);
+  pocs_sincos_small(d, &sd, &cd, V);
   const int s = n & 255;
   const double C = T->sc[s][0], S = T->sc[s][1];
   *sn = fma(S, cd, C * sd);
@@ -309,7 +314,7 @@ POCS_HD void pocs_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint
 // device: the compiler's own f64 expansion (v_rsq_f64 seed, one coupled Goldschmidt step, two
 // residual corrections) without the 2^+-256 range scaling it wraps around it for arguments below
 // 2^-767 and without its select for +-0 / inf: t = |-2 log u| is never 0 (the smallest value, at
-// u = 1, is the rounding error 4e-19 of the table log; every other word gives >= 4.6e-10 --
+// u = 1, is a rounding error of the table form, ~1e-16; every other word gives >= 4.6e-10 --
 // pinned by tests/test_product_host_vs_oracle.py) and never exceeds 44.4.
 POCS_HD double pocs_sqrt_radius2(double t) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -333,9 +338,9 @@ POCS_HD double pocs_sqrt_radius2(double t) {
 // u = (wr + 1) 2^-32 in (0,1], radius = sqrt(-2 log u) <= sqrt(64 ln 2) < 6.661 (the bound the
 // obstacle culling of k_gmm_step relies on), one word for the angle 2 pi wa 2^-32.
 POCS_HD void pocs_normal_pair_w2(uint32_t wr, uint32_t wa, const pocs_tables* T, double* n0, double* n1, const pocs_vconst* V = nullptr) {
-  // |.|: at u = 1 (wr = 2^32 - 1) the table form of log may land a rounding error (1e-19) ABOVE
-  // zero; the radius is then ~1e-9 instead of 0, never the square root of a negative number
-  const double rad = pocs_sqrt_radius2(fabs(-2.0 * pocs_log_unit32(wr, T, V)));
+  // |.|: at u = 1 (wr = 2^32 - 1) the table form lands a rounding error (~1e-16) on EITHER side of
+  // zero; the radius is then ~1e-8 instead of 0, never the square root of a negative number
+  const double rad = pocs_sqrt_radius2(fabs(pocs_radius2_unit32(wr, T)));
   double sn, cs;
   pocs_sincos_2pi_u32_tab(wa, T, &sn, &cs, V);
   *n0 = rad * cs;

@@ -14,7 +14,7 @@ static const pocs_tables* tabs() {
 }
 
 extern "C" {
-double hh_log_unit32(uint32_t w) { return pocs_log_unit32(w, tabs()); }
+double hh_radius2_unit32(uint32_t w) { return pocs_radius2_unit32(w, tabs()); }
 void hh_normal_pair_w2(uint32_t wr, uint32_t wa, double* n0, double* n1) { pocs_normal_pair_w2(wr, wa, tabs(), n0, n1); }
 void hh_sincos_tab(double x, double* s, double* c) { pocs_sincos_tab(x, tabs(), s, c); }
 void hh_sincos_2pi_u32_tab(uint32_t w, double* s, double* c) { pocs_sincos_2pi_u32_tab(w, tabs(), s, c); }

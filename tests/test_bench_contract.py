@@ -48,7 +48,7 @@ def test_full_size_line_carries_the_counter_records():
     """At the workload's own size the line carries the committed PMC figures: HBM bytes per launch (close to the
     algorithmic 26 B/eval) and the vector instructions per evaluation with the issue fraction they imply."""
     recs = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-    if not any(v.get("numerics") == "v7" and v.get("evals_per_launch") == 20_000_000 for v in recs.values()):
+    if not any(v.get("numerics") == "v8" and v.get("evals_per_launch") == 20_000_000 for v in recs.values()):
         pytest.skip("no counter record of the current numerics at this launch size yet")
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
                          capture_output=True, text=True, check=True, cwd=str(ROOT))
@@ -125,20 +125,6 @@ def test_two_ranks_on_one_card_take_the_onehop_path():
     assert d["config"]["total_samples_per_run"] == 40000
     one = run_bench("--no-cpu-baseline", "--samples", "40000", "--steps", "4")       # later flags win: N = 40000, 4 steps
     assert d["config"]["probability"] == one["config"]["probability"]
-
-
-def test_unequal_shares_of_the_two_blocks_of_a_cu_change_no_bit():
-    """POCS_GMM_SKEW (sweeps): the first 256 blocks of a 512-block launch get more units than the rest.  Which block
-    adds which unit changes no bit of any result: the probability of the last run of the 20-run call is the same."""
-    import os
-    base = None
-    for skew in ("500", "570", "640"):
-        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
-                             capture_output=True, text=True, check=True, cwd=str(ROOT),
-                             env=dict(os.environ, POCS_GMM_SKEW=skew, POCS_SKIP_SINGLE="1", POCS_NO_BOARD_PROBE="1"))
-        d = json.loads(out.stdout.splitlines()[-1])
-        base = base or d["config"]["probability"]
-        assert d["config"]["probability"] == base and 0.0 < base < 1.0, (skew, d["config"]["probability"], base)
 
 
 def test_two_ranks_through_the_collective_path():

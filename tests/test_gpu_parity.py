@@ -306,38 +306,31 @@ def test_graph_replays_survive_readbacks(pocs, plan, env, mc):
 
 
 def test_sub_batches_on_side_streams_change_no_bit(tmp_path):
-    """POCS_GMM_GROUPS = 2, 3: a call's runs issued as sub-batches on side streams (graph forked and joined by
-    events; eager too), their launches overlapping: every run's probabilities and moments as with one launch per
-    waypoint for all of them."""
+    """POCS_OPT_SUB_BATCHES = 2: a call's runs issued as two sub-batches on streams of their own (graph forked and
+    joined by events; eager too), their launches overlapping: every run's probabilities and moments as with one
+    launch per waypoint for all of them.  Three and more lost on the clock and are refused."""
     import hashlib
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
-    root = Path(__file__).resolve().parents[1]
-    code = (
-        "import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
-        "import pocs_amd\n"
-        "plan, env = pocs_amd.load_plan(), pocs_amd.load_env()\n"
-        "h = hashlib.sha256()\n"
-        "with pocs_amd.Context(0) as c:\n"
-        "    for graph in (1, 0):\n"
-        "        c.configure(plan, env, K=3, N=100001, seed=5)\n"
-        "        c.set_option(pocs_amd.OPT_USE_GRAPH, graph)\n"
-        "        c.set_batch(17)\n"
-        "        for rep in range(2):\n"
-        "            c.run_gmm_estimation()\n"
-        "            h.update(np.array(c.batch_probabilities()).tobytes())\n"
-        "            for r in (0, 8, 16):\n"
-        "                c.select_batch_run(r)\n"
-        "                h.update(np.array([c.moments(w, 3) for w in range(56)]).tobytes())\n"
-        "print(h.hexdigest())\n" % str(root))
+    import pocs_amd
+    plan, env = pocs_amd.load_plan(), pocs_amd.load_env()
     digests = {}
-    for g in ("1", "2", "3"):
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True,
-                             env=dict(os.environ, POCS_GMM_GROUPS=g))
-        digests[g] = out.stdout.strip().splitlines()[-1]
-    assert digests["1"] == digests["2"] == digests["3"], digests
+    for g in (1, 2):
+        h = hashlib.sha256()
+        with pocs_amd.Context(0) as c:
+            for graph in (1, 0):
+                c.configure(plan, env, K=3, N=100001, seed=5)
+                c.set_option(pocs_amd.OPT_USE_GRAPH, graph)
+                c.set_option(pocs_amd.OPT_SUB_BATCHES, g)
+                c.set_batch(17)
+                for rep in range(2):
+                    c.run_gmm_estimation()
+                    h.update(np.array(c.batch_probabilities()).tobytes())
+                    for r in (0, 8, 16):
+                        c.select_batch_run(r)
+                        h.update(np.array([c.moments(w, 3) for w in range(56)]).tobytes())
+            with pytest.raises(pocs_amd.PocsError):
+                c.set_option(pocs_amd.OPT_SUB_BATCHES, 3)
+        digests[g] = h.hexdigest()
+    assert digests[1] == digests[2], digests
 
 
 def test_batch_equals_consecutive_single_runs(ctx, plan, env):
@@ -506,7 +499,7 @@ def test_degenerate_mixtures_match_oracle(ctx, orc, plan, env, K, N):
         p = ctx.run_gmm_estimation()
         want = orc.run_gmm(cfg, seed, N)
         assert np.array_equal(ctx.waypoint_probabilities(), want["probs"])
-        assert abs(p - want["prob"]) < 1e-15
+        assert p == want["prob"]
         got_alive = np.array([ctx.gmm_state(w, K)[3] for w in range(cfg.W)])
         assert np.array_equal(got_alive, want["states"][:, :, 13])
         assert np.array_equal(np.array([ctx.gmm_state(w, K)[2] for w in range(cfg.W)]), want["states"][:, :, 12])
@@ -527,7 +520,7 @@ def test_limits_of_the_boundary(ctx, pocs, orc, plan):
         ctx.configure(pl, env64, params=params, K=3, N=3000, seed=4)
         p = ctx.run_gmm_estimation()
         want = orc.run_gmm(cfg, 4, 3000, want_samples=True)
-        assert np.array_equal(ctx.gmm_samples(3000)[1], want["flags"]) and abs(p - want["prob"]) < 1e-12
+        assert np.array_equal(ctx.gmm_samples(3000)[1], want["flags"]) and p == want["prob"]
         ctx.set_seed(4)
         assert ctx.run_simulation() == orc.run_mc(cfg, 4, 3000)[0] / 3000
     with pytest.raises(pocs.PocsError):
@@ -571,7 +564,7 @@ def test_randomised_configurations_match_oracle(ctx, pocs, orc, plan):
         p = ctx.run_gmm_estimation()
         want = orc.run_gmm(cfg, seed, N, want_samples=True)
         assert np.array_equal(ctx.waypoint_probabilities(), want["probs"]), case
-        assert abs(p - want["prob"]) < 1e-12, case
+        assert p == want["prob"], case
         assert np.array_equal(ctx.gmm_samples(N)[1], want["flags"]), case
         ctx.set_seed(seed)
         p_mc = ctx.run_simulation()
@@ -608,7 +601,7 @@ def test_text_channel_is_a_drop_in(ctx, pocs, orc, plan, env):
     finally:
         c.close()
     cfg = orc.config(plan, env, K=3)
-    assert abs(p_gmm - orc.run_gmm(cfg, 99, 3000)["prob"]) < 1e-12
+    assert p_gmm == orc.run_gmm(cfg, 99, 3000)["prob"]
     assert p_mc == orc.run_mc(cfg, 99, 3000)[0] / 3000
 
 
@@ -706,7 +699,7 @@ def test_graphs_survive_buffer_growth(pocs, orc, plan, env):
         c.set_option(pocs.OPT_RUN_AHEAD, 16)
         c.set_seed(77)
         p = c.run_gmm_estimation()                              # R = 16: d_hdr / d_chain are replaced
-        assert abs(p - orc.run_gmm(cfg, 77, N)["prob"]) <= 2.0 / N
+        assert p == orc.run_gmm(cfg, 77, N)["prob"]
         c.set_option(pocs.OPT_RUN_AHEAD, 1)
         c.set_seed(77)
         assert c.mc_run_local() == n0
@@ -724,7 +717,7 @@ def test_rotated_obstacles_and_offset_footprint(ctx, orc, plan):
     p = ctx.run_gmm_estimation()
     want = orc.run_gmm(cfg, 3, 6000, want_samples=True)
     assert np.array_equal(ctx.gmm_samples(6000)[1], want["flags"])
-    assert abs(p - want["prob"]) < 1e-12
+    assert p == want["prob"]
     ctx.set_seed(3)
     assert ctx.run_simulation() == orc.run_mc(cfg, 3, 6000)[0] / 6000
 
@@ -822,21 +815,22 @@ def test_run_ahead_with_alternating_paths(pocs, plan, env):
     assert one == ahead
 
 
-def test_mc_nontemporal_instantiation_matches(ctx, orc, plan, env, monkeypatch):
+def test_mc_nontemporal_instantiation_matches(pocs, ctx, orc, plan, env):
     """k_mc_step<NT>: the instantiation the host selects once a batch's particle state exceeds the
-    Infinity Cache (too big for this suite), forced here through the sweep override: same hit
+    Infinity Cache (too big for this suite), forced here through POCS_OPT_MC_NONTEMPORAL: same hit
     counters and particles as the oracle, and as the plain instantiation."""
     N = 5001
     cfg = orc.config(plan, env, K=1)
     results = {}
     for nt in ("0", "1"):
-        monkeypatch.setenv("POCS_MC_NT", nt)
         ctx.configure(plan, env, K=1, N=N, seed=SEED + 7)       # a setter: the launch graph is captured again
+        ctx.set_option(pocs.OPT_MC_NONTEMPORAL, int(nt))
         ctx.set_num_particles(N)
         p = ctx.run_simulation()
         xyz, hits = ctx.particles(N)
         results[nt] = (p, xyz.copy(), hits.copy())
     n_mc, want_hits, _ = orc.run_mc(cfg, SEED + 7, N)
+    ctx.set_option(pocs.OPT_MC_NONTEMPORAL, -1)
     for nt in ("0", "1"):
         assert results[nt][0] == n_mc / N and np.array_equal(results[nt][2], want_hits)
     assert np.array_equal(results["0"][1], results["1"][1])

@@ -45,34 +45,37 @@ def test_normal3_bitwise(hh, orc):
 
 
 def test_table_functions_bitwise_and_accurate(hh, orc):
-    """The table-driven log / sincos of the hot path: product == oracle bit for bit, and both
-    within ~1 ulp of libm."""
-    hh.hh_log_unit32.restype = C.c_double
-    hh.hh_log_unit32.argtypes = [C.c_uint32]
+    """The table-driven radius / sincos of the hot path (numerics v8): product == oracle bit for bit, and both
+    accurate to a few 1e-16 ABSOLUTE against libm -- six orders below the 4.7e-10 between two neighbouring levels
+    of the 32-bit word the squared radius is a function of."""
+    hh.hh_radius2_unit32.restype = C.c_double
+    hh.hh_radius2_unit32.argtypes = [C.c_uint32]
     rng = np.random.default_rng(21)
     ws = [0, 1, 2, 2 ** 32 - 1, 2 ** 32 - 2, 2 ** 31, 2 ** 31 - 1] + [int(v) for v in rng.integers(0, 2 ** 32, 20000)] + \
-         [int(v) for v in rng.integers(0, 2 ** 12, 2000)]
-    worst = 0.0
+         [int(v) for v in rng.integers(0, 2 ** 12, 2000)] + [2 ** 32 - 1 - int(v) for v in rng.integers(0, 2 ** 12, 2000)]
+    worst_abs, worst_rel = 0.0, 0.0
     for w in ws:
-        got = hh.hh_log_unit32(w)
-        assert got == orc.log_unit32(w)
-        want = math.log((w + 1) * 2.0 ** -32)      # (w + 1) * 2^-32 is exact in binary64
-        # absolute accuracy (what the radius sqrt(-2 log u) needs); near u = 1 the table form
-        # cancels, so its RELATIVE error there is larger than the polynomial form's -- harmless
-        worst = max(worst, abs(got - want) / max(abs(want), 1.0))
-    assert worst < 3e-16, worst
-    assert 0.0 < abs(hh.hh_log_unit32(2 ** 32 - 1)) < 2e-16      # u = 1: radius ~0, but never exactly 0 (the device
-    assert all(abs(hh.hh_log_unit32(2 ** 32 - 1 - j)) > 2e-10 for j in range(1, 1000))    # sqrt sequence divides by it)
-    assert math.sqrt(-2 * hh.hh_log_unit32(0)) < 6.661           # the bound the obstacle culling uses
+        got = hh.hh_radius2_unit32(w)
+        assert got == orc.radius2_unit32(w)
+        want = -2.0 * math.log1p(-(2 ** 32 - 1 - w) * 2.0 ** -32)      # u = 1 - (2^32 - 1 - w) 2^-32, exact; log1p keeps u near 1 accurate
+        worst_abs = max(worst_abs, abs(got - want))
+        worst_rel = max(worst_rel, abs(got - want) / max(abs(want), 1.0))
+    assert worst_rel < 6e-16 and worst_abs < 8e-15, (worst_rel, worst_abs)      # (v7: 3e-16 on the logarithm = 6e-16 here; 8e-15: an ulp of the largest value, 44.4)
+    assert 0.0 < abs(hh.hh_radius2_unit32(2 ** 32 - 1)) < 1e-15   # u = 1: radius ~0, but never exactly 0 (the device
+    assert all(hh.hh_radius2_unit32(2 ** 32 - 1 - j) > 4e-10 for j in range(1, 1000))    # sqrt sequence divides by it)
+    assert math.sqrt(hh.hh_radius2_unit32(0)) < 6.661             # the bound the obstacle culling uses
     s, c = C.c_double(), C.c_double()
-    for x in np.concatenate([rng.uniform(-20, 20, 8000), rng.uniform(-1e4, 1e4, 1000), [0.0, -0.0, 6.283185307179586, 1.5707963267948966]]):
+    for x in np.concatenate([rng.uniform(-20, 20, 8000), rng.uniform(-1e4, 1e4, 1000), [0.0, -0.0, 6.283185307179586, 1.5707963267948966],
+                             (np.arange(-300, 300) + 0.5) * (math.pi / 128)]):       # (sector edges: rint's ties)
         hh.hh_sincos_tab(C.c_double(x), C.byref(s), C.byref(c))
         assert (s.value, c.value) == orc.sincos_tab(float(x))
         assert abs(s.value - math.sin(x)) < 4e-16 * max(1.0, abs(x) / 10) and abs(c.value - math.cos(x)) < 4e-16 * max(1.0, abs(x) / 10)
-    for w in np.concatenate([rng.integers(0, 2 ** 32, 8000), [0, 2 ** 26 - 1, 2 ** 26, 2 ** 25, 2 ** 32 - 1, 2 ** 31]]):
+    for w in np.concatenate([rng.integers(0, 2 ** 32, 8000), [0, 2 ** 26 - 1, 2 ** 26, 2 ** 25, 2 ** 32 - 1, 2 ** 31, 2 ** 23, 2 ** 23 - 1]]):
         hh.hh_sincos_2pi_u32_tab(C.c_uint32(int(w)), C.byref(s), C.byref(c))
         assert (s.value, c.value) == orc.sincos_2pi_u32_tab(int(w))
-        ws, wc = orc.sincos_2pi_u32(int(w))              # the polynomial version, itself within 2.3e-16 of libm
+        # v8: the word's angle turned back by half a sector, i.e. the angle of the word w - 2^23 (mod 2^32), whose
+        # polynomial version is itself within 2.3e-16 of libm and has no range reduction to round
+        ws, wc = orc.sincos_2pi_u32((int(w) - 2 ** 23) & 0xFFFFFFFF)
         assert abs(s.value - ws) < 4e-16 and abs(c.value - wc) < 4e-16
         assert abs(s.value ** 2 + c.value ** 2 - 1.0) < 6e-16
 
@@ -94,7 +97,7 @@ def test_box_muller_radius_edge_words(hh, orc):
             assert (a.value, b.value) == orc.normal_pair_w2(wr, wa), (wr, wa)
             assert a.value ** 2 + b.value ** 2 < 6.661 ** 2
     hh.hh_normal_pair_w2(C.c_uint32(2 ** 32 - 1), C.c_uint32(123), C.byref(a), C.byref(b))
-    assert abs(a.value) < 1e-8 and abs(b.value) < 1e-8           # u = 1: radius 0 up to the log's rounding
+    assert abs(a.value) < 4e-8 and abs(b.value) < 4e-8           # u = 1: radius 0 up to the table form's rounding
 
 
 def test_sample_pairs_bitwise(hh, orc):
