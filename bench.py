@@ -144,8 +144,16 @@ def cpu_baseline(plan, env, K, W, path, budget_evals, budget_s=None):
         out["all_cores"] = threaded(share, n)
         out["all_cores"]["note"] = "one GPU's share of this host (POCS_CPU_THREADS, default 16)"
     if ncpu > share:                                                      # ... and the whole host: every core the process may use
-        out["host_cores"] = threaded(ncpu, max(1000, n // 2))
+        # (the same total work as the leg above, spread over all of them: on the pool's boxes the affinity mask shows
+        # the whole host while a cgroup quota holds the process to one GPU's share of it -- `cgroup_cpu_limit` says so,
+        # and the figure then reads BELOW the 16-thread one: oversubscription, not a slower host)
+        out["host_cores"] = threaded(ncpu, max(1000, n * share // ncpu))
         out["host_cores"]["note"] = "every core of the host this process may run on (sched_getaffinity)"
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            out["host_cores"]["cgroup_cpu_limit"] = None if quota == "max" else float(quota) / float(period)
+        except (OSError, ValueError):
+            out["host_cores"]["cgroup_cpu_limit"] = None
     return out
 
 
@@ -487,12 +495,25 @@ def main():
                 made.append(make(b_lo, 0x5EED0002))
             ctx = made[0][0]
             engines = []
+            # The launches as they run in production -- the replayed graph -- between ONE pair of hipEvents per call, for
+            # every call of the timed region (POCS_OPT_PROFILE = 2): span / W = the mean launch period of the hot kernel,
+            # its duration plus the gap to the next launch.  (Events around EVERY launch, the eager form further down,
+            # keep the command processor from preparing a launch under the running one: ~9 us more per launch.)
+            span = {"ms": 0.0, "n": 0, "on": False}
+            if not args.mc_fused and os.environ.get("POCS_NO_GRAPH") != "1" and hasattr(ctx.lib, "pocs_get_exchange_wait"):
+                for c, _ in made:
+                    c.set_option(pocs_amd.OPT_PROFILE, 2)
+                span["on"] = True
 
             def run_steps(sizes):
                 p = 0.0
                 for b in sizes:
                     c = made[0][0] if b == b_hi else made[1][0]
                     p = c.run_gmm_estimation() if path == "gmm" else c.run_simulation()
+                    if span["on"] and b == b_hi:
+                        ms, n = c.kernel_time()
+                        span["ms"] += ms
+                        span["n"] += n
                 return p
         else:
             # one rank per GPU: two engines on two streams take the calls in turn, so one engine's
@@ -560,6 +581,8 @@ def main():
             if dist is not None:
                 d = over_ranks([d], dist.ReduceOp.MAX)[0]
             return d, p
+        if not sharded:
+            span["ms"], span["n"] = 0.0, 0             # (the warm-up's spans are not the timed region's)
         d0, prob = timed_pass()                        # (`probability` = the last run of the FIRST repeat: reproducible)
         repeats = int(min(200, max(10, math.ceil(TIMED_TARGET_S / max(d0, 1e-6))))) if full else 3
         dts = [d0] + [timed_pass()[0] for _ in range(repeats - 1)]
@@ -575,6 +598,8 @@ def main():
 
         # roofline of the dominant kernel: further calls with the hot kernel bracketed by hipEvents on
         # the launch stream (eager launches; not part of `value`)
+        if not sharded:
+            span["on"] = False                             # (the totals of the timed region stay)
         ctx.set_option(pocs_amd.OPT_PROFILE, 1)
         ms_tot, n_launch, groups, waypoint_us = 0.0, 0, 1, None
         for _ in range(max(1, min(len(chunks), 3))):
@@ -593,7 +618,14 @@ def main():
             if path == "gmm" and not engines and hasattr(ctx.lib, "pocs_get_sequence_time"):      # (an A/B library of an older commit has none)
                 seq_ms, groups = ctx.sequence_time()
                 waypoint_us = seq_ms * 1e3 / W
-        res["avg_ms"] = ms_tot / max(n_launch, 1)
+        res["bracketed_ms"] = ms_tot / max(n_launch, 1)            # events around every launch (eager)
+        res["avg_ms"], res["duration_is"] = res["bracketed_ms"], "hipEvents around every launch of the hot kernel (eager launches), mean"
+        if not sharded and span["n"] > 0:
+            res["avg_ms"] = span["ms"] / span["n"]
+            res["duration_is"] = ("mean launch period inside the replayed graph over every call of the timed region: one pair of hipEvents around "
+                                  "each graph launch, span / launches -- the kernel's duration PLUS the gap to the next launch (an upper bound of "
+                                  "the duration; the rocprofv3 trace under profiles/ has the durations themselves); `bracketed_kernel_us` = "
+                                  "events around every single launch instead, which costs each launch the dispatch it otherwise overlaps")
         res["groups"], res["waypoint_us"] = groups, waypoint_us
         # sharded through the library's exchange: how long this rank's closers waited for the other ranks' moments in
         # that last call, per (run, waypoint)
@@ -608,6 +640,8 @@ def main():
         # rate -- the two meet at the board's power cap; not part of `value`
         res["nostore_ms"] = None
         if full and path == "gmm" and not engines and os.environ.get("POCS_NO_STORE") != "1":
+            if res["avg_ms"] is not res["bracketed_ms"]:         # timed the same way as the launches it is set beside
+                ctx.set_option(pocs_amd.OPT_PROFILE, 2)
             ctx.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
             run_steps([b_hi])                            # (the graph / buffers of this variant)
             t_ms, t_n = 0.0, 0
@@ -770,7 +804,8 @@ def main():
                 "copy_GBps": copy_gbps, "frac_of_copy": achieved / copy_gbps if (copy_gbps or 0) > 0 else None,
                 "fill_GBps": fill_gbps, "frac_of_fill": achieved / fill_gbps if (fill_gbps or 0) > 0 else None,
                 "algorithmic_bytes_per_launch": bpe * units, "bytes_per_eval": bpe, "evals_per_launch": units,
-                "avg_kernel_us": avg_ms * 1e3, "concurrent_launches": groups, "waypoint_us": res["waypoint_us"],
+                "avg_kernel_us": avg_ms * 1e3, "duration_is": res["duration_is"], "bracketed_kernel_us": res["bracketed_ms"] * 1e3,
+                "concurrent_launches": groups, "waypoint_us": res["waypoint_us"],
                 "evals_per_s_in_kernel": units / (avg_ms * 1e-3) if avg_ms > 0 else 0.0}
     if path == "mc" and not args.mc_fused:
         roofline["resident"] = "infinity-cache" if mc_resident else "hbm"

@@ -71,7 +71,10 @@ int pocs_send_command(pocs_ctx* ctx, const char* line, char* out, size_t cap);
 #define POCS_OPT_STORE_SAMPLES 1   /* 1 (default): GMM samples + flags are written to HBM (26 B/eval, auditable); 0: not stored */
 #define POCS_OPT_MC_FUSED 2        /* 0 (default): one launch per waypoint, particles streamed through HBM (56 B/eval); 1: whole roll-out in registers */
 #define POCS_OPT_USE_GRAPH 3       /* 1 (default): the per-run launch sequence is replayed from a hipGraph */
-#define POCS_OPT_PROFILE 4         /* 1: bracket the hot kernel with hipEvents (see pocs_get_kernel_time) */
+#define POCS_OPT_PROFILE 4         /* 1: bracket every launch of the hot kernel with hipEvents (eager launches; see pocs_get_kernel_time).  An event
+                                      between two kernels costs the bracketed kernel ~9 us of dispatch that back-to-back launches overlap.
+                                      2 (whole-run GMM calls): the replayed graph as it runs in production between one pair of events;
+                                      pocs_get_kernel_time then returns the span and W, i.e. the mean launch PERIOD (duration + gap) */
 #define POCS_OPT_RUN_AHEAD 5       /* R > 1, or 0 = R sized per call from the sample / particle count (8..64: the reference's 200 runs
                                       of 10^4 samples go 64 at a time, a 10^6-sample estimation 16 at a time); default 1 = off.
                                       With one run per call (batch 1), a run* call evaluates the NEXT R

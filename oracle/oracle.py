@@ -12,7 +12,8 @@ from pathlib import Path
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-LIB = HERE / "libpocs_oracle.so"
+SANITIZE = os.environ.get("POCS_SANITIZE") == "1"      # tests/Makefile `sanitize`: the ASan + UBSan build of the same file
+LIB = HERE / ("libpocs_oracle_san.so" if SANITIZE else "libpocs_oracle.so")
 
 MAX_K, MAX_L, NMOM, STATE = 8, 32, 11, 16
 STREAM_CHAIN, STREAM_MCINIT, STREAM_GMM = 1, 2, 3
@@ -29,7 +30,7 @@ class OrcConfig(C.Structure):
 def build(force=False):
     src = HERE / "pocs_oracle.c"
     if force or not LIB.exists() or LIB.stat().st_mtime < src.stat().st_mtime:
-        subprocess.run(["make", "-C", str(HERE), "libpocs_oracle.so"], check=True,
+        subprocess.run(["make", "-C", str(HERE), LIB.name], check=True,
                        stdout=subprocess.DEVNULL)
     return LIB
 

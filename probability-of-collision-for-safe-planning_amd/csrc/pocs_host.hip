@@ -113,6 +113,7 @@ struct pocs_ctx {
   bool env_dirty = true, sensor_dirty = true;
 
   hipGraphExec_t graph_gmm = nullptr, graph_mc = nullptr;
+  const void* graph_baked[3] = {nullptr, nullptr, nullptr};   // diagnostic build only (POCS_GRAPH_WITH_COPIES)
   std::string graph_gmm_key, graph_mc_key;
 
   std::vector<hipEvent_t> events;
@@ -386,7 +387,7 @@ double* moments_dev(pocs_ctx* c) { return c->ext_moments ? c->ext_moments : (dou
 
 int prof_begin(pocs_ctx* c, size_t launches) {
   c->prof_ms = 0.0; c->prof_launches = 0;
-  if (!c->opt_profile) return POCS_OK;
+  if (c->opt_profile != 1) return POCS_OK;
   while (c->events.size() < 2 * launches) {
     hipEvent_t e;
     HIPCHK(c, hipEventCreate(&e));
@@ -395,7 +396,7 @@ int prof_begin(pocs_ctx* c, size_t launches) {
   return POCS_OK;
 }
 int prof_collect(pocs_ctx* c, size_t launches) {
-  if (!c->opt_profile) return POCS_OK;
+  if (c->opt_profile != 1) return POCS_OK;
   for (size_t i = 0; i < launches; ++i) {
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->events[2 * i], c->events[2 * i + 1]));
@@ -724,16 +725,30 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
   lap("prepared");
   if (int r = gmm_upload_run(c)) return r;
   lap("upload enqueued");
-  const bool prof = c->opt_profile != 0;
+  // POCS_OPT_PROFILE: 1 = events around every launch of the hot kernel (eager launches: an event between two kernels
+  // keeps the command processor from preparing the next launch under the running one, which adds ~9 us to what it
+  // brackets); 2 = the replayed graph as it runs in production between ONE pair of events outside it: span / W is the
+  // mean launch PERIOD -- duration plus the gap to the next launch --, an upper bound of the mean duration.
+  const bool prof = c->opt_profile == 1, span = c->opt_profile == 2 && c->opt_graph;
   if (int r = prof_begin(c, gmm_hot_launches(c))) return r;
-  if (int r = enqueue_ticket_reset(c)) return r;
+#if defined(POCS_TUNING) && defined(POCS_GRAPH_WITH_COPIES)      // diagnostic build: round 2's graph shape (the memset and the two result copies as graph nodes)
+  const bool copies_in_graph = c->opt_graph && !prof;
+#else
+  const bool copies_in_graph = false;
+#endif
+  if (!copies_in_graph) if (int r = enqueue_ticket_reset(c)) return r;
   if (c->opt_graph && !prof) {
     const std::string key = config_key(c, first, count, "gmm");
     if (!c->graph_gmm || key != c->graph_gmm_key) {
       if (c->graph_gmm) { hipGraphExecDestroy(c->graph_gmm); c->graph_gmm = nullptr; }
       hipGraph_t g = nullptr;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      int r = enqueue_gmm_all(c, first, count, false);
+      int r = copies_in_graph ? enqueue_ticket_reset(c) : POCS_OK;
+      if (!r) r = enqueue_gmm_all(c, first, count, false);
+      if (!r && copies_in_graph) r = enqueue_gmm_results(c);
+      if (copies_in_graph) {                           // the pointers the memset / memcpy nodes bake in: a stale one would show here
+        c->graph_baked[0] = c->d_ticket.p; c->graph_baked[1] = c->h_pin; c->graph_baked[2] = moments_dev(c);
+      }
       hipError_t e = hipStreamEndCapture(c->stream, &g);
       if (r) { if (g) hipGraphDestroy(g); return r; }
       HIPCHK(c, e);
@@ -742,21 +757,26 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
       HIPCHK(c, e);
       c->graph_gmm_key = key;
     }
+    if (copies_in_graph && (c->graph_baked[0] != c->d_ticket.p || c->graph_baked[1] != c->h_pin || c->graph_baked[2] != moments_dev(c)))
+      return fail(c, POCS_E_STATE, "a pointer baked into the graph's memset / memcpy nodes changed between capture and replay");
+    if (span) HIPCHK(c, hipEventRecord(c->ev_seq[0], c->stream));
     HIPCHK(c, hipGraphLaunch(c->graph_gmm, c->stream));
+    if (span) HIPCHK(c, hipEventRecord(c->ev_seq[1], c->stream));
   } else {
     if (int r = enqueue_gmm_all(c, first, count, prof)) return r;
   }
-  if (int r = enqueue_gmm_results(c)) return r;
+  if (!copies_in_graph) if (int r = enqueue_gmm_results(c)) return r;
   lap("launched");
   prefetch_next_batch(c);          // host chains of the next batch, while the GPU works on this one
   lap("next batch prepared");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   lap("synchronised");
   if (int r = prof_collect(c, gmm_hot_launches(c))) return r;
-  if (prof) {
+  if (prof || span) {
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_seq[0], c->ev_seq[1]));
     c->seq_ms = ms; c->seq_groups = gmm_groups(c);
+    if (span) { c->prof_ms = ms; c->prof_launches = (long long)gmm_hot_launches(c); }      // pocs_get_kernel_time: span / W
   }
   {
     unsigned gave_up = 0;
@@ -836,7 +856,7 @@ int run_mc_local(pocs_ctx* c) {
   if (int r = ensure(c, c->d_total, R * sizeof(unsigned long long) + 16)) return r;
   if (int r = ensure_pin(c)) return r;
   if (int r = stage_and_upload_runs(c)) return r;
-  const bool prof = c->opt_profile != 0;
+  const bool prof = c->opt_profile == 1, span = c->opt_profile == 2 && c->opt_graph;      // (as run_gmm_full)
   const size_t nprof = c->opt_fused ? 1 : (W > 1 ? W - 1 : 0);
   if (int r = prof_begin(c, nprof > 0 ? nprof : 1)) return r;
   // (the counter reset ahead of the launches and the result copy behind them are plain stream operations: the
@@ -857,7 +877,9 @@ int run_mc_local(pocs_ctx* c) {
       HIPCHK(c, e);
       c->graph_mc_key = key;
     }
+    if (span) HIPCHK(c, hipEventRecord(c->ev_seq[0], c->stream));
     HIPCHK(c, hipGraphLaunch(c->graph_mc, c->stream));
+    if (span) HIPCHK(c, hipEventRecord(c->ev_seq[1], c->stream));
   } else {
     if (int r = enqueue_mc_all(c, first, count, prof)) return r;
   }
@@ -867,6 +889,11 @@ int run_mc_local(pocs_ctx* c) {
   prefetch_next_batch(c);          // host chains of the next batch, while the GPU works on this one
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (int r = prof_collect(c, nprof)) return r;
+  if (span) {                                          // the graph's span over its W - 1 hot launches (+ the init and count launches: an upper bound)
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_seq[0], c->ev_seq[1]));
+    c->prof_ms = ms; c->prof_launches = (long long)(nprof > 0 ? nprof : 1);
+  }
   c->mc_counts.resize(R);
   memcpy(c->mc_counts.data(), (double*)c->h_pin + pl.total, R * sizeof(unsigned long long));
   c->last_mc_count = count;
@@ -1115,7 +1142,10 @@ int pocs_set_option(pocs_ctx* c, int option, long long value) {
     case POCS_OPT_STORE_SAMPLES: c->opt_store = value ? 1 : 0; break;
     case POCS_OPT_MC_FUSED: c->opt_fused = value ? 1 : 0; break;
     case POCS_OPT_USE_GRAPH: c->opt_graph = value ? 1 : 0; break;
-    case POCS_OPT_PROFILE: c->opt_profile = value ? 1 : 0; break;
+    case POCS_OPT_PROFILE:
+      if (value < 0 || value > 2) return fail(c, POCS_E_ARG, "POCS_OPT_PROFILE takes 0, 1 or 2");
+      c->opt_profile = value;
+      break;
     case POCS_OPT_PERSISTENT:
       // the queue-driven whole-call kernel (k_gmm_run) of round 2 was retired in round 3: slower than one launch per
       // waypoint at every batch size measured, and not worth a second summation shape
@@ -1317,7 +1347,7 @@ int pocs_gmm_sample_local(pocs_ctx* c, int w) {
   if (w != c->last_gmm_adv) return fail(c, POCS_E_ORDER, "waypoint %d sampled before pocs_gmm_advance_local(%d)", w, w);
   long long first, count;
   if (int r = gmm_shard(c, &first, &count)) return r;
-  if (int r = enqueue_step(c, first, count, w, false, c->opt_profile ? w : -1)) return r;
+  if (int r = enqueue_step(c, first, count, w, false, c->opt_profile == 1 ? w : -1)) return r;
   c->last_gmm_wp = w;
   c->last_gmm_count = count;
   return POCS_OK;
@@ -1411,7 +1441,7 @@ int pocs_gmm_sample_exchange_local(pocs_ctx* c, int w) {
   a.xchg.world = c->xchg_world; a.xchg.rank = c->xchg_rank;
   a.xchg.epoch = (c->xchg_calls << 20) | (unsigned long long)(w + 1);
   a.xchg.parity = (int)((c->xchg_calls * (unsigned long long)c->W + (unsigned long long)w) & 1ull);
-  const int slot = c->opt_profile ? w : -1;
+  const int slot = c->opt_profile == 1 ? w : -1;
   if (slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * slot], c->stream));
   HIPCHK(c, pocs_launch_gmm_step(c->K, a, c->stream));
   if (slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * slot + 1], c->stream));
@@ -1502,6 +1532,9 @@ int pocs_get_host_chain(pocs_ctx* c, double* applied3, double* noisy3, double* z
 // would otherwise pin the caller's pageable pages on the fly for every call).
 #define POCS_COPY_CHUNK (4u << 20)
 static int copy_out(pocs_ctx* c, void* dst, const void* src_dev, size_t bytes, size_t elem, size_t dst_stride) {
+#if defined(POCS_TUNING) && defined(POCS_PAGEABLE_GETTERS)      // diagnostic build: round 2's getters (the runtime pins the caller's pages per call)
+  if (dst_stride == 0 || dst_stride == elem) { HIPCHK(c, hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost)); return POCS_OK; }
+#endif
   if (!c->h_copy) HIPCHK(c, hipHostMalloc(&c->h_copy, POCS_COPY_CHUNK, hipHostMallocDefault));
   for (size_t off = 0; off < bytes; off += POCS_COPY_CHUNK) {
     const size_t n = bytes - off < POCS_COPY_CHUNK ? bytes - off : POCS_COPY_CHUNK;

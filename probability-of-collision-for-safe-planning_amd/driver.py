@@ -84,14 +84,17 @@ def summary(props, times):
 
 
 def run_experiment(simoption, num_runs=200, num_particles=10000, num_gaussians=3, seed=1, device=0,
-                   plan=None, env=None, envfile=None, params=None, out_dir=".", stamp=None, batch=1, run_ahead=1):
+                   plan=None, env=None, envfile=None, params=None, out_dir=".", stamp=None, batch=1, run_ahead=0):
     """MCSimulation.py:221-269.  Returns dict(times, proportions, journal, report, summary).
 
     batch=1 issues one run per command like the reference.  batch=R (ours) advances R of the
     independent runs per command in lockstep on the GPU (pocs_set_batch): same runs, same seeds,
     same journal and report; a run's simTime is then its call's wall time / R.
-    run_ahead=R (ours) keeps one command per run but lets the library evaluate the next R runs in
-    one launch (setRunAhead): same runs again; the first command of a group carries the group's time."""
+    run_ahead keeps one command per run -- the reference's loop, unchanged -- but lets the library evaluate the next R
+    runs in one launch and answer the following commands from it (setRunAhead): 0 (the default, as in the OpenRAVE
+    adapter) = R sized by the library from the sample count (64 at the reference's own 10^4 samples), 1 = off, one
+    launch per run.  Same runs, same seeds, same journal, bit for bit (tests/test_driver.py); a command's simTime is
+    what that command took -- the first of a group does the group's work, the others return at once."""
     if simoption not in ("MC", "GMM"):
         raise ValueError('simoption must be "MC" or "GMM"')              # MCSimulation.py:108-111
     plan = plan or planio.load_plan()
@@ -112,14 +115,10 @@ def run_experiment(simoption, num_runs=200, num_particles=10000, num_gaussians=3
         command = "runSimulation" if simoption == "MC" else "runGMMEstimation"
         batch = max(1, int(batch))
         i = 0
-        while i < num_runs:
-            b = min(batch, num_runs - i)
-            if batch > 1:
-                mod.set_batch(b)
-            start = time.perf_counter()
-            collprop = float(mod.SendCommand(command))
-            sim_time = (time.perf_counter() - start) / b
-            for p in ([collprop] if batch == 1 else [float(v) for v in mod.batch_probabilities()]):
+
+        def journal_runs(entries):
+            nonlocal i
+            for sim_time, p in entries:
                 times.append(sim_time)
                 props.append(p)
                 f2.write("Simulation: " + str(i) + "\n")
@@ -128,6 +127,18 @@ def run_experiment(simoption, num_runs=200, num_particles=10000, num_gaussians=3
                 i += 1
             f2.flush()
             os.fsync(f2.fileno())
+
+        while i < num_runs:
+            b = min(batch, num_runs - i)
+            if batch > 1:
+                mod.set_batch(b)
+            start = time.perf_counter()
+            collprop = float(mod.SendCommand(command))
+            wall = time.perf_counter() - start
+            # (run-ahead: a command's simTime is what THAT command took, as the reference's loop measures it -- the command
+            # that launched a group carries the group's work, the ones answered from it take microseconds; their mean, the
+            # report's "Average Sim Time", is the experiment's time per run either way)
+            journal_runs([(wall / b, float(v)) for v in mod.batch_probabilities()] if batch > 1 else [(wall, collprop)])
     write_report(report, simoption, envfile, params, num_runs, num_particles, plan, times, props, num_gaussians)
     return dict(times=times, proportions=props, journal=journal, report=report, summary=summary(props, times))
 
@@ -142,7 +153,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--batch", type=int, default=1, help="runs advanced in lockstep per command (1 = like the reference)")
-    ap.add_argument("--run-ahead", type=int, default=1, help="one command per run, the next R runs evaluated in one launch")
+    ap.add_argument("--run-ahead", type=int, default=0, help="one command per run, the next R runs evaluated in one launch (0 = sized by the library, 1 = off)")
     ap.add_argument("--plan", default=None)
     ap.add_argument("--env", default=None)
     ap.add_argument("--out", default=".")

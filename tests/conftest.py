@@ -11,6 +11,12 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "oracle"))
 
 
+# `make -C tests sanitize`: the host-side helpers are built with AddressSanitizer + UBSan under other names
+SANITIZE = __import__("os").environ.get("POCS_SANITIZE") == "1"
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-g"] if SANITIZE else []
+SAN_SUFFIX = "_san" if SANITIZE else ""
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -41,12 +47,12 @@ def env(pocs):
 def hh():
     """Product inline functions compiled for the host (tests/host_harness.cpp)."""
     src = Path(__file__).with_name("host_harness.cpp")
-    out = Path(__file__).with_name("_host_harness.so")
+    out = Path(__file__).with_name("_host_harness%s.so" % SAN_SUFFIX)
     csrc = ROOT / "probability-of-collision-for-safe-planning_amd" / "csrc"
     deps = [src] + [csrc / n for n in ("pocs_math.h", "pocs_model.h", "pocs_collide.h")]
     if not out.exists() or any(d.stat().st_mtime > out.stat().st_mtime for d in deps):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma",
-                        str(src), "-o", str(out)], check=True)
+        subprocess.run(["g++", "-O1" if SANITIZE else "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma"] + SAN_FLAGS +
+                       [str(src), "-o", str(out)], check=True)
     lib = C.CDLL(str(out))
     lib.hh_log.restype = C.c_double
     lib.hh_log.argtypes = [C.c_double]

@@ -28,8 +28,14 @@ def test_default_line_has_every_field():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert sum(d["config"]["calls"]) == 5
+    # SURVEY 8d's protocol: the median of >= 10 repeats of the timed pass, the spread beside it
+    t = d["timing"]
+    assert t["repeats"] >= 10 and t["ms_per_step_min"] <= t["ms_per_step_median"] <= t["ms_per_step_max"]
+    assert d["ms_per_step"] == t["ms_per_step_median"] and t["timed_region_s"] > 0
+    assert d["numerics"].startswith("v8") and "numerics v8" in d["numerics"] and "Philox4x32-7" in d["config"]["random_stream"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # the limiter names the bound; the fraction is still the north star's: algorithmic bytes against the HBM peak
+    assert r["bound"] == "fp64-issue+power" and r["reported_against"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert r["algorithmic_bytes_per_launch"] == 26 * r["evals_per_launch"]
     # 100 000 evaluations per launch here: no committed counter record within 2 x of that -> no extrapolated traffic
@@ -42,6 +48,9 @@ def test_default_line_has_every_field():
     if (ROOT / "oracle" / "_ref" / "libpocs_ref_loop.so").exists():
         assert c["kind"] == "reference" and c["port"]["kind"] == "port" and c["port"]["value"] > 0, c
     assert d["value"] > 0 and abs(d["value"] - 20000 * 56 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-9
+    # one GPU's share of the host and, where the host has more, every core the process may use; sized to the GPU part
+    assert c["all_cores"]["cores"] <= 16 and ("host_cores" not in c or c["host_cores"]["cores"] == c["nproc"] > c["all_cores"]["cores"])
+    assert "budget" in c
 
 
 def test_full_size_line_carries_the_counter_records():
@@ -73,6 +82,13 @@ def test_strong_scaling_line():
 def test_mc_workload_line():
     d = run_bench("--workload", "mc", "--no-cpu-baseline")
     assert "MC" in d["metric"] and d["roofline"]["bytes_per_eval"] == 56 and "cpu_baseline" not in d
+    # 64 roll-outs of 20 000 particles = 36 MB of state: resident in the Infinity Cache between launches, so the line
+    # does not call its bytes per second an HBM fraction
+    r = d["roofline"]
+    assert r["resident"] == "infinity-cache" and r["bound"] == "infinity-cache" and r["frac"] is None and r["achieved"] > 0
+    d = run_bench("--workload", "mc", "--no-cpu-baseline", "--samples", "1200000", "--batch", "8", "--steps", "8", "--warmup", "8")
+    r = d["roofline"]                                  # 8 x 1.2e6 x 28 B = 269 MB: past the cache, the non-temporal kernel, an HBM fraction
+    assert r["resident"] == "hbm" and r["bound"] == "hbm" and 0.2 < r["frac"] < 1.0
 
 
 def test_sharded_path_on_one_rank_prints_one_line():
@@ -96,6 +112,17 @@ def test_gpus_2_started_by_hand_brings_up_its_own_ranks():
                                                                 POCS_SKIP_SINGLE="1", POCS_NO_BOARD_PROBE="1"))
     assert d["n_gpus"] == 2 and d["config"]["total_samples_per_run"] == 40000 and "tail" in d["config"]["exchange"]
     assert len(d["roofline"]["ranks_kernel_us"]["all"]) == 2
+    # a scaling run that explains itself: the probe's outcome and time, the closers' waits for the other rank's moments
+    # (in-kernel clock), the ranks' kernel times and their spread -- and the strong-scaling workload riding along
+    assert d["exchange_probe"]["ok"] is True and d["exchange_probe"]["seconds"] > 0
+    xw = d["exchange_wait_us"]
+    assert xw["available"] and 0 <= xw["min_us"] <= xw["median_us"]["median"] <= xw["max_us"] and len(xw["median_us"]["per_rank"]) == 2
+    assert "ONE CARD" in xw["status"]                            # values of a rehearsal: unmeasured on hardware
+    assert d["roofline"]["skew_us"] == d["roofline"]["ranks_kernel_us"]["max"] - d["roofline"]["ranks_kernel_us"]["min"]
+    st = d["strong"]
+    assert st["scaling"] == "strong" and "cfg3" in st["workload"] and st["value"] > 0 and st["ms_per_step"] > 0
+    assert len(st["ranks_kernel_us"]["all"]) == 2 and "tail" in st["exchange"] and st["exchange_wait_us"]["available"]
+    assert 0.0 < st["probability"] < 1.0
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                          capture_output=True, text=True, cwd=str(ROOT), env=env)
     assert out.returncode != 0 and out.stdout.strip() == "" and "refusing" in out.stderr

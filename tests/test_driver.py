@@ -58,11 +58,17 @@ def test_driver_batched_runs_are_the_same_runs(driver, tmp_path, mode):
 
 @pytest.mark.gpu
 def test_driver_run_ahead_is_transparent(driver, tmp_path):
-    """run_ahead=R: still one command per run (the reference's loop), same proportions."""
-    one = driver.run_experiment("MC", num_runs=7, num_particles=2500, seed=5, out_dir=tmp_path / "one")
+    """run_ahead=R: still one command per run (the reference's loop), same proportions -- for R = 3, for the default
+    (0: sized by the library, 64 at this size) and for 1 (off: one launch per run)."""
+    one = driver.run_experiment("MC", num_runs=7, num_particles=2500, seed=5, out_dir=tmp_path / "one", run_ahead=1)
     ra = driver.run_experiment("MC", num_runs=7, num_particles=2500, seed=5, out_dir=tmp_path / "ra", run_ahead=3)
-    assert one["proportions"] == ra["proportions"]
-    assert len(ra["journal"].read_text().splitlines()) == 21
+    auto = driver.run_experiment("MC", num_runs=7, num_particles=2500, seed=5, out_dir=tmp_path / "auto")
+    assert one["proportions"] == ra["proportions"] == auto["proportions"]
+    assert len(ra["journal"].read_text().splitlines()) == 21 and len(auto["journal"].read_text().splitlines()) == 21
+    g1 = driver.run_experiment("GMM", num_runs=70, num_particles=3000, seed=6, out_dir=tmp_path / "g1", run_ahead=1)
+    g0 = driver.run_experiment("GMM", num_runs=70, num_particles=3000, seed=6, out_dir=tmp_path / "g0")      # two groups of 64
+    assert g1["proportions"] == g0["proportions"] and len(set(g0["proportions"])) == 70
+    assert sum(g0["times"]) < sum(g1["times"])
 
 
 @pytest.mark.gpu

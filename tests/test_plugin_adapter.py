@@ -10,9 +10,11 @@ from pathlib import Path
 
 import pytest
 
+from conftest import SAN_FLAGS, SAN_SUFFIX
+
 ROOT = Path(__file__).resolve().parents[1]
 PKG = ROOT / "probability-of-collision-for-safe-planning_amd"
-EXE = ROOT / "tests" / "_plugin_demo"
+EXE = ROOT / "tests" / ("_plugin_demo" + SAN_SUFFIX)
 
 
 @pytest.fixture(scope="module")
@@ -22,7 +24,7 @@ def demo(pocs):
     deps = [src, ROOT / "plugin" / "mcsimplugin_pocs.cpp", PKG / "csrc" / "mcmodule.hpp", PKG / "csrc" / "scene_boxes.hpp",
             ROOT / "include" / "pocs.h", ROOT / "tests" / "openrave_shim" / "openrave" / "plugin.h"]
     if not EXE.exists() or any(d.stat().st_mtime > EXE.stat().st_mtime for d in deps):
-        subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-I" + str(ROOT / "tests" / "openrave_shim"), str(src), "-o", str(EXE),
+        subprocess.run(["g++", "-O1", "-std=c++17"] + SAN_FLAGS + [ "-Wall", "-I" + str(ROOT / "tests" / "openrave_shim"), str(src), "-o", str(EXE),
                         "-L" + str(PKG), "-lpocs", "-Wl,-rpath," + str(PKG), "-Wl,-rpath,/opt/rocm/lib"], check=True)
     return EXE
 
