@@ -116,7 +116,14 @@ int pocs_select_batch_run(pocs_ctx* ctx, int run);   /* the getters below (waypo
 
 /* ---- sharding over GPUs (one process per GPU; the caller owns the collective) -----------
  * A context evaluates global sample / particle indices [first, first+count) of the N configured;
- * random draws are keyed by the GLOBAL index so results do not depend on the partition. */
+ * random draws are keyed by the GLOBAL index, so every sample, flag, survivor count and hit counter is the same
+ * whatever the partition.  The moment SUMS of the GMM path are another matter: each shard adds its samples in its own
+ * summation tree (a function of the shard's sample count: 512-pair chunks, at most 256 virtual slices -- part of the
+ * numerics version pocs_version() names) and the ranks' totals are added in rank order, so the sums of a sharded run
+ * differ from the one-GPU run's in their last bits (a different order of the same additions): bit-equality of sums,
+ * mixture states and probabilities holds PER SHARD SIZE -- the same world size and shards reproduce bit for bit --,
+ * not across world sizes (8 shards of cfg3 against one GPU: all counts equal, final probability equal, sums within
+ * 8e-10 of their scale). */
 int pocs_set_shard(pocs_ctx* ctx, long long first, long long count);   /* (-1, -1) = the whole range again */
 int pocs_set_stream(pocs_ctx* ctx, void* hip_stream);                 /* launch on this stream (e.g. a torch stream).  NULL = back to the context's
                                                                           own NON-BLOCKING stream -- not the null stream: a caller whose

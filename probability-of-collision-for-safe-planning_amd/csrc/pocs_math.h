@@ -310,13 +310,14 @@ POCS_HD void pocs_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint
   *spare = a.w;
 }
 
-// sqrt for 0 < t <= 64 (the squared Box-Muller radius), correctly rounded like sqrt().  On the
+// sqrt for positive t in the normal range -- the squared Box-Muller radius (0 < t <= 64), and the distances and pivots
+// of pocs_model.h --, correctly rounded like sqrt().  On the
 // device: the compiler's own f64 expansion (v_rsq_f64 seed, one coupled Goldschmidt step, two
 // residual corrections) without the 2^+-256 range scaling it wraps around it for arguments below
 // 2^-767 and without its select for +-0 / inf: t = |-2 log u| is never 0 (the smallest value, at
 // u = 1, is a rounding error of the table form, ~1e-16; every other word gives >= 4.6e-10 --
 // pinned by tests/test_product_host_vs_oracle.py) and never exceeds 44.4.
-POCS_HD double pocs_sqrt_radius2(double t) {
+POCS_HD double pocs_sqrt_normal(double t) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const double y = __builtin_amdgcn_rsq(t);
   double g = t * y;
@@ -334,13 +335,44 @@ POCS_HD double pocs_sqrt_radius2(double t) {
 #endif
 }
 
+// Division and square root of the O(1)-per-waypoint estimator math (pocs_model.h: truncated moments, EKF update,
+// Cholesky) as one wave executes them between two sampling launches, where every instruction of the serial chain is
+// exposed latency: the compiler's own IEEE expansions -- v_rcp_f64 / v_rsq_f64 seed, Newton steps, one or two residual
+// corrections -- WITHOUT the v_div_scale / v_div_fmas / v_div_fixup wrapping (the 2^+-256 scaling for sqrt) that
+// guards operands near the ends of the exponent range and infinities: covariances, distances and counts are nowhere
+// near them, and for such operands the guarded and the bare sequence execute the same arithmetic on the same values
+// -- the correctly rounded quotient / root that `/` and sqrt() give on the host.  pocs_recip_seed is the refined
+// reciprocal a group of quotients with one denominator shares.
+POCS_HD double pocs_recip_seed(double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(b);
+  double e = fma(-b, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-b, y, 1.0);
+  return fma(y, e, y);
+#else
+  return b;                                        // (host: the denominator itself; pocs_div_by then divides)
+#endif
+}
+POCS_HD double pocs_div_by(double a, double b, double seed) {      // a / b; seed = pocs_recip_seed(b)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double q = a * seed;
+  const double r = fma(-b, q, a);
+  return fma(r, seed, q);
+#else
+  (void)seed;
+  return a / b;
+#endif
+}
+POCS_HD double pocs_div(double a, double b) { return pocs_div_by(a, b, pocs_recip_seed(b)); }
+
 // Box-Muller pair of the mixture sampler, through the tables: one word for the radius,
 // u = (wr + 1) 2^-32 in (0,1], radius = sqrt(-2 log u) <= sqrt(64 ln 2) < 6.661 (the bound the
 // obstacle culling of k_gmm_step relies on), one word for the angle 2 pi wa 2^-32.
 POCS_HD void pocs_normal_pair_w2(uint32_t wr, uint32_t wa, const pocs_tables* T, double* n0, double* n1, const pocs_vconst* V = nullptr) {
   // |.|: at u = 1 (wr = 2^32 - 1) the table form lands a rounding error (~1e-16) on EITHER side of
   // zero; the radius is then ~1e-8 instead of 0, never the square root of a negative number
-  const double rad = pocs_sqrt_radius2(fabs(pocs_radius2_unit32(wr, T)));
+  const double rad = pocs_sqrt_normal(fabs(pocs_radius2_unit32(wr, T)));
   double sn, cs;
   pocs_sincos_2pi_u32_tab(wa, T, &sn, &cs, V);
   *n0 = rad * cs;

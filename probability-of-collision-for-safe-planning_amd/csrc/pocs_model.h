@@ -84,13 +84,14 @@ POCS_HD void pocs_ekf_update(double mu[3], double S[9], const double* z, const p
     const double dx = mu[0] - sen->lx[l];          // == -(lx - mu0), makeHRow's numerator
     const double dy = mu[1] - sen->ly[l];
     const double q = dx * dx + dy * dy;
-    const double sq = sqrt(q);
-    const double H0 = dx / sq;
-    const double H1 = dy / sq;
+    const double sq = pocs_sqrt_normal(q);                 // (device: the bare sequences of pocs_math.h; the same values)
+    const double rsq = pocs_recip_seed(sq);
+    const double H0 = pocs_div_by(dx, sq, rsq);
+    const double H1 = pocs_div_by(dy, sq, rsq);
     const double hs0 = H0 * S[0] + H1 * S[3];
     const double hs1 = H0 * S[1] + H1 * S[4];
     const double sinn = (hs0 * H0 + hs1 * H1) + sen->Q;
-    const double sinv = 1.0 / sinn;
+    const double sinv = pocs_div(1.0, sinn);
     const double K0 = (S[0] * H0 + S[1] * H1) * sinv;
     const double K1 = (S[3] * H0 + S[4] * H1) * sinv;
     const double K2 = (S[6] * H0 + S[7] * H1) * sinv;
@@ -117,16 +118,17 @@ POCS_HD void pocs_ekf_update(double mu[3], double S[9], const double* z, const p
 POCS_HD int pocs_chol3_lower(const double S[9], double L[6]) {
   const double d0 = S[0];
   if (!(d0 > 0.0)) return 0;
-  const double l00 = sqrt(d0);
-  const double l10 = S[3] / l00;
-  const double l20 = S[6] / l00;
+  const double l00 = pocs_sqrt_normal(d0);
+  const double r00 = pocs_recip_seed(l00);
+  const double l10 = pocs_div_by(S[3], l00, r00);
+  const double l20 = pocs_div_by(S[6], l00, r00);
   const double d1 = S[4] - l10 * l10;
   if (!(d1 > 0.0)) return 0;
-  const double l11 = sqrt(d1);
-  const double l21 = (S[7] - l20 * l10) / l11;
+  const double l11 = pocs_sqrt_normal(d1);
+  const double l21 = pocs_div(S[7] - l20 * l10, l11);
   const double d2 = (S[8] - l20 * l20) - l21 * l21;
   if (!(d2 > 0.0)) return 0;
-  L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = sqrt(d2);
+  L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = pocs_sqrt_normal(d2);
   return 1;
 }
 
@@ -139,14 +141,16 @@ POCS_HD int pocs_truncated_moments(const double* mom, double mean[3], double cov
   const double n = mom[0];
   if (!(n >= 2.0)) return 0;
   const double sx = mom[2], sy = mom[3], st = mom[4];
-  mean[0] = sx / n; mean[1] = sy / n; mean[2] = st / n;
+  const double rn = pocs_recip_seed(n);                   // fifteen quotients, two denominators
+  mean[0] = pocs_div_by(sx, n, rn); mean[1] = pocs_div_by(sy, n, rn); mean[2] = pocs_div_by(st, n, rn);
   const double nm1 = n - 1.0;
-  const double cxx = (mom[5] - (sx * sx) / n) / nm1;
-  const double cxy = (mom[6] - (sx * sy) / n) / nm1;
-  const double cxt = (mom[7] - (sx * st) / n) / nm1;
-  const double cyy = (mom[8] - (sy * sy) / n) / nm1;
-  const double cyt = (mom[9] - (sy * st) / n) / nm1;
-  const double ctt = (mom[10] - (st * st) / n) / nm1;
+  const double rm = pocs_recip_seed(nm1);
+  const double cxx = pocs_div_by(mom[5] - pocs_div_by(sx * sx, n, rn), nm1, rm);
+  const double cxy = pocs_div_by(mom[6] - pocs_div_by(sx * sy, n, rn), nm1, rm);
+  const double cxt = pocs_div_by(mom[7] - pocs_div_by(sx * st, n, rn), nm1, rm);
+  const double cyy = pocs_div_by(mom[8] - pocs_div_by(sy * sy, n, rn), nm1, rm);
+  const double cyt = pocs_div_by(mom[9] - pocs_div_by(sy * st, n, rn), nm1, rm);
+  const double ctt = pocs_div_by(mom[10] - pocs_div_by(st * st, n, rn), nm1, rm);
   cov[0] = cxx; cov[1] = cxy; cov[2] = cxt;
   cov[3] = cxy; cov[4] = cyy; cov[5] = cyt;
   cov[6] = cxt; cov[7] = cyt; cov[8] = ctt;
