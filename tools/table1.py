@@ -23,11 +23,15 @@ PAPER = {"MC": (0.9348, 0.0406, 81.93), "GMM1": (0.6364, 0.0699, 72.58), "GMM2":
 ref = None
 if oracle.RefLoop.LIB.exists():
     ref = oracle.RefLoop(oracle.Oracle(), pocs_amd, pocs_amd.load_plan(), pocs_amd.load_env())
-print("%-6s %28s   %42s   %34s" % ("method", "this build (mean sd  s/run)", "reference loop, compiled (mean sd  CPU-s/run)",
-                                   "paper Table I (mean sd  CPU-s/run)"))
+print("%-6s %28s %26s   %42s   %34s" % ("method", "this build (mean sd  s/run)", "[200 runs: s; run_ahead=1: s]", "reference loop, compiled (mean sd  CPU-s/run)",
+                                        "paper Table I (mean sd  CPU-s/run)"))
 with tempfile.TemporaryDirectory() as tmp:
     for name, mode, K in (("MC", "MC", 3), ("GMM1", "GMM", 1), ("GMM2", "GMM", 2), ("GMM3", "GMM", 3)):
+        # one command per run, as the reference's loop issues them; the library evaluates 64 runs per launch behind it
+        # (run_ahead = 0, the driver's default since round 4) -- and, for the record, one launch per run (run_ahead = 1)
         r = driver.run_experiment(mode, num_runs=200, num_particles=10000, num_gaussians=K, seed=2018, out_dir=tmp)
+        r1 = driver.run_experiment(mode, num_runs=200, num_particles=10000, num_gaussians=K, seed=2018, out_dir=tmp, run_ahead=1)
+        assert r1["proportions"] == r["proportions"]
         s = r["summary"]
         p = PAPER[name]
         rs = (float("nan"),) * 3
@@ -36,4 +40,5 @@ with tempfile.TemporaryDirectory() as tmp:
             t0 = time.perf_counter()
             v = np.array([ref.time_mc(100 + i) if mode == "MC" else ref.run_gmm(100 + i, gen_seed=900 + i)["p"] for i in range(200)])
             rs = (v.mean(), v.std(ddof=1), (time.perf_counter() - t0) / 200)
-        print("%-6s %10.4f %8.4f %9.6f   %22.4f %8.4f %9.4f   %14.4f %8.4f %9.2f" % (name, s["mean"], s["std"], s["mean_time"], *rs, *p))
+        print("%-6s %10.4f %8.4f %9.6f %12.4f %12.4f   %22.4f %8.4f %9.4f   %14.4f %8.4f %9.2f" % (
+            name, s["mean"], s["std"], s["mean_time"], sum(r["times"]), sum(r1["times"]), *rs, *p))
