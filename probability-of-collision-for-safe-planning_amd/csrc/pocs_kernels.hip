@@ -912,15 +912,19 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
     for (int j = tid; j < 2 * NW * K; j += TB) (&sm.xj[0][0][0])[j] = -1;
     if (tid == 0) sm.seed[0] = a.hdr[r0].seed;
     double* const l_mom = advance_ptrs(a, K, w, r0, sm.adv()).l_mom;
+    // (the obstacle table, one element per thread, requested with everything else: it lands in the transpose scratch as soon
+    // as the row sums are done with it, under the components' serial chain instead of in a round trip of its own behind it)
+    static_assert(POCS_MAX_OBSTACLES * POCS_OBS_STRIDE <= TB, "one obstacle element per thread");
+    const double obs_elem = tid < a.M * POCS_OBS_STRIDE ? a.env->obs[tid] : 0.0;
     gmm_close_sums<K, TB>(a, w - 1, r0, sm.par[1], sm.stage(), l_mom, tid, a.partial_prev, out);   // ... with the rows'
     POCS_STAMP(5);
+    if (tid < a.M * POCS_OBS_STRIDE) sm.obs()[tid] = obs_elem;      // (every read of the staging rows lies behind a barrier of gmm_close_sums)
     advance_block(a, K, w, r0, sm.adv(), sm.spec(), true, tid, TB, true, out);
     __syncthreads();
     POCS_STAMP(6);
     POCS_STAMP_COUNT(14);
     const double* const l_par = advance_ptrs(a, K, w, r0, sm.adv()).l_par;
     for (int j = tid; j < PS; j += TB) sm.par[0][j] = l_par[j];
-    for (int j = tid; j < a.M * POCS_OBS_STRIDE; j += TB) sm.obs()[j] = a.env->obs[j];     // (the staging rows are done with)
   } else {
     for (int j = tid; j < a.M * POCS_OBS_STRIDE; j += TB) sm.obs()[j] = a.env->obs[j];
     for (int j = tid; j < (r1 - r0 + 1) * K * POCS_PARAM_STRIDE; j += TB)   // param[r][w][..]: the two runs' records are a.W records apart

@@ -2,7 +2,7 @@
 """Extended differential run of the HIP path against the CPU oracle: random worlds (rotated boxes,
 off-centre footprints, noise levels, landmark sets, sub-plans, K, N, seeds, batches), more and larger
 than tests/test_gpu_parity.py::test_randomised_configurations_match_oracle affords in the suite.
-Checks per case, ALL exact (numerics v7: the oracle restates the summation tree): moments, mixture states and
+Checks per case, ALL exact (since numerics v7: the oracle restates the summation tree): moments, mixture states and
 probabilities of every waypoint, the last waypoint's flags, of run 0 and of the last run of a random batch;
 hit counters of the MC path.  usage: fuzz_parity.py [cases] [max_N] [seed]"""
 import sys

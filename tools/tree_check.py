@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU check of the summation tree (numerics v7): moments of every waypoint against the oracle's tree order --
+"""GPU check of the summation tree (numerics v7 and later): moments of every waypoint against the oracle's tree order --
 bit for bit -- and a run's bits at 1 / 20 / 64 runs per launch and under run-ahead.  usage: tree_check.py [N]"""
 import sys
 import time
