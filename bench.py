@@ -621,7 +621,8 @@ def main():
                 waypoint_us = seq_ms * 1e3 / W
         res["bracketed_ms"] = ms_tot / max(n_launch, 1)            # events around every launch (eager)
         res["avg_ms"], res["duration_is"] = res["bracketed_ms"], "hipEvents around every launch of the hot kernel (eager launches), mean"
-        if not sharded and span["n"] > 0:
+        res["span_timed"] = (not sharded) and span["n"] > 0
+        if res["span_timed"]:
             res["avg_ms"] = span["ms"] / span["n"]
             res["duration_is"] = ("mean launch period inside the replayed graph over every call of the timed region: one pair of hipEvents around "
                                   "each graph launch, span / launches -- the kernel's duration PLUS the gap to the next launch (an upper bound of "
@@ -641,7 +642,7 @@ def main():
         # rate -- the two meet at the board's power cap; not part of `value`
         res["nostore_ms"] = None
         if full and path == "gmm" and not engines and os.environ.get("POCS_NO_STORE") != "1":
-            if res["avg_ms"] is not res["bracketed_ms"]:         # timed the same way as the launches it is set beside
+            if res["span_timed"]:                                # timed the same way as the launches it is set beside
                 ctx.set_option(pocs_amd.OPT_PROFILE, 2)
             ctx.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
             run_steps([b_hi])                            # (the graph / buffers of this variant)
@@ -728,7 +729,7 @@ def main():
         # default workload holds -- so that the launch's fixed cost and the exchange weigh as they do there)
         # (the one-card rehearsal keeps 16: two ranks' 512-block launches do not fit ONE card side by side, and a closer
         # that waits for a rank whose launch cannot start waits for its 30 s)
-        sruns = 16 if "POCS_FORCE_DEVICE" in os.environ else 64
+        sruns = int(os.environ.get("POCS_STRONG_RUNS", "16" if "POCS_FORCE_DEVICE" in os.environ else "64"))
         sres = measure("cfg3", "strong", sruns, sruns, sruns, args.samples, False)
         kus = sres["ranks_kernel_us"] or []
         strong_rec = {"workload": "cfg3 split over %d GPUs (BASELINE configs[3] at 8): %d samples per GPU per run of %d in total, W=%d, K=%d, %d runs per call"

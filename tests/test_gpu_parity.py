@@ -858,3 +858,37 @@ def test_default_bench_shape_properties(pocs, plan, env):
             ps.append(p)
         assert len(set(ps)) == R and all(0.0 < p < 1.0 for p in ps)
         assert abs(np.mean(ps) - 0.2857) < 0.02          # this build's own level (profiles/r01_table1_like.txt, GMM3): a regression pin
+
+
+def test_span_profile_times_the_replayed_graph(pocs, plan, env):
+    """POCS_OPT_PROFILE = 2: one pair of events around the replayed graph of a whole-run call -- what bench.py divides
+    by W for the launch period of the hot kernel.  The results do not change, the span covers W launches, and it is
+    no longer than W launches bracketed one by one (POCS_OPT_PROFILE = 1, eager)."""
+    K, N = 3, 200000
+    with pocs.Context(0) as c:
+        c.configure(plan, env, K=K, N=N, seed=SEED)
+        c.set_batch(4)
+        p0 = c.run_gmm_estimation()
+        c.set_seed(SEED)
+        c.set_option(pocs.OPT_PROFILE, 2)
+        c.run_gmm_estimation()                                   # (captures the graph again: a setter was called)
+        c.set_seed(SEED)
+        p2 = c.run_gmm_estimation()
+        ms2, n2 = c.kernel_time()
+        c.set_seed(SEED)
+        c.set_option(pocs.OPT_PROFILE, 1)
+        p1 = c.run_gmm_estimation()
+        ms1, n1 = c.kernel_time()
+        c.set_seed(SEED)
+        c.set_option(pocs.OPT_PROFILE, 0)
+        c.set_num_particles(N)
+        c.set_option(pocs.OPT_PROFILE, 2)
+        c.run_simulation()
+        c.set_seed(SEED)
+        c.run_simulation()
+        msm, nm = c.kernel_time()
+        with pytest.raises(pocs.PocsError):
+            c.set_option(pocs.OPT_PROFILE, 3)
+    assert p0 == p1 == p2
+    assert n2 == n1 == 56 and 0.0 < ms2 < 1.25 * ms1
+    assert nm == 55 and msm > 0.0
