@@ -480,6 +480,8 @@ def main():
                 c.set_option(pocs_amd.OPT_MC_FUSED, 1)
             if os.environ.get("POCS_NO_STORE") == "1":       # tuning only: samples not written to HBM
                 c.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
+            if os.environ.get("POCS_SUB_BATCHES"):           # tuning only: a call's runs as two sub-batches on two streams
+                c.set_option(pocs_amd.OPT_SUB_BATCHES, int(os.environ["POCS_SUB_BATCHES"]))
             if os.environ.get("POCS_NO_GRAPH") == "1":       # diagnostic builds that synchronise inside the launch sequence
                 c.set_option(pocs_amd.OPT_USE_GRAPH, 0)
             if sharded:     # one rank per GPU: launches on a torch stream, moments in a torch tensor
@@ -749,7 +751,8 @@ def main():
     bpe = BYTES_PER_EVAL_GMM if path == "gmm" else BYTES_PER_EVAL_MC
     # a call may be issued as G sub-batches whose launches run side by side (POCS_OPT_SUB_BATCHES, default 1): the events
     # bracket sub-batch 0's launches, each of which works on batch / G runs
-    units = n_local * batch // max(groups, 1)       # evaluations one launch of the hot kernel processes
+    # (span-timed: the period is that of a waypoint of the WHOLE call, all sub-batches side by side, and so are the bytes)
+    units = n_local * batch // (1 if res.get("span_timed") else max(groups, 1))       # evaluations per launch (period)
     achieved = (bpe * units) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # Committed counter records of this workload (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction applied;
     # profiles/traffic.json with its sources): HBM bytes and vector instructions per launch.  The record nearest in launch

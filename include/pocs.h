@@ -91,10 +91,11 @@ int pocs_send_command(pocs_ctx* ctx, const char* line, char* out, size_t cap);
                                       the previous waypoint in every block's head instead of tickets and a closing block (no one else
                                       is in flight to hide a closer behind): 10 % less time per waypoint, the same bits
                                       (tests/test_gpu_parity.py::test_lone_call_changes_no_bit).  0: the ticket form always. */
-#define POCS_OPT_SUB_BATCHES 8     /* 1 (default) or 2: a whole-run call's runs issued as that many sub-batches on streams of their own, so that one
-                                      sub-batch's launch tail is covered by the other's sampling blocks.  The moment sums are defined on a run's
-                                      virtual slices, not on the launch: no bit of any result changes.  Measured +0.5 % at 20 runs per call,
-                                      +2.5 % at 64 (three and four lost and are refused): off by default. */
+#define POCS_OPT_SUB_BATCHES 8     /* 0 (default): a whole-run call of >= 8 runs and >= 1.2e6 evaluations per waypoint is issued as TWO sub-batches
+                                      on two streams, so that one sub-batch's launch tail (its last blocks' slow end, the serial mixture advance
+                                      of its last closer, the launch boundary) is covered by the other's sampling blocks: +4 ... +11 % measured;
+                                      smaller calls as one launch per waypoint.  1 / 2 force one form.  The moment sums are defined on a run's
+                                      virtual slices, not on the launch: no bit of any result changes. */
 #define POCS_OPT_MC_NONTEMPORAL 9  /* -1 (default): k_mc_step streams past the caches when the batch's particle state (28 B per particle)
                                       exceeds the 256 MB Infinity Cache and uses plain accesses when it fits; 0 / 1 force one form.
                                       Same results either way. */

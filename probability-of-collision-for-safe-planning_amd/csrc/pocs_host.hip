@@ -69,7 +69,7 @@ struct pocs_ctx {
   std::vector<double> boxes;             // M x 5
   bool have_obstacles = false;           // pocs_set_obstacles / addObstacle / clearObstacles was called at least once
   long long shard_first = -1, shard_count = -1;
-  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0, opt_lone = 1, opt_groups = 1, opt_mc_nt = -1;
+  long long opt_store = 1, opt_fused = 0, opt_graph = 1, opt_profile = 0, opt_lone = 1, opt_groups = 0, opt_mc_nt = -1;
   unsigned long long epoch = 0;          // bumped by every setter; part of the graph cache key
   int batch = 1;                         // independent GMM estimations advanced in lockstep per call
   // run-ahead (POCS_OPT_RUN_AHEAD): with batch == 1 a run* call evaluates the next `run_ahead` runs
@@ -611,13 +611,23 @@ int enqueue_ticket_reset(pocs_ctx* c) {
 size_t gmm_hot_launches(const pocs_ctx* c) { return (size_t)c->W; }
 
 // Sub-batches of a whole-run call (above).  The moment sums do not depend on the launch shape (pocs_kernels.hip,
-// "summation tree"), so a split changes no bit of any result.  One by default: measured on MI355X (round 3, 10^6
-// samples, K = 3, same box) two sub-batches gave +0.5 % at 20 runs per call and +2.5 % at 64, three and four lost --
-// the launches' tails are mostly blocks of unequal speed, which a second kernel in flight does not fix.
-// POCS_OPT_SUB_BATCHES = 1 (default) or 2 (tests/test_gpu_parity.py checks the bits).
+// "summation tree"), so a split changes no bit of any result.  TWO sub-batches on two streams by default where a call
+// has the work for it (round 4, measured on MI355X with numerics v8, 10^6 samples, K = 3, one box, three alternations and
+// a sweep, profiles/r04_sub_batches.txt): while one sub-batch is in the tail of its waypoint -- the slow end of its last
+// blocks, the serial mixture advance of its last closer, the launch boundary, the next launch's heads -- the other's
+// sampling blocks have the chip: +11 % at 8 runs per call, +7 % at 16 and 20, +6 % at 32, +4 % at 64; K = 8, 10^7
+// samples, 16 runs: +4 %.  Below 8 runs per call a launch of half the runs does not fill the chip (-5 ... -23 % at 2 ... 6
+// runs), and launches of less than ~6 x 10^5 evaluations are all dispatch (64 runs of 10^4 samples: -15 %): one launch
+// for all then.  Three sub-batches lose everywhere, four gain less than two.  (Round 3 had measured +0.5 % at 20 runs
+// for the same split and left it off: its closers were a third longer and it timed one pass, not a median.)
+// POCS_OPT_SUB_BATCHES: 0 = this rule (default), 1, 2 (tests/test_gpu_parity.py checks the bits).
 int gmm_groups(const pocs_ctx* c) {
-  if (c->ext_moments) return 1;
+  if (c->ext_moments) return 1;                      // sharded: the caller's exchange covers the whole batch at once
   int g = (int)c->opt_groups;
+  if (g == 0) {
+    const double count = (double)(c->shard_first >= 0 ? c->shard_count : c->num_gmm);
+    g = (c->batch >= 8 && (double)c->batch * count >= 1.2e6) ? 2 : 1;
+  }
   if (g > c->batch) g = c->batch;
   return g < 1 ? 1 : g;
 }
@@ -1153,7 +1163,7 @@ int pocs_set_option(pocs_ctx* c, int option, long long value) {
       break;
     case POCS_OPT_LONE_CALL: c->opt_lone = value ? 1 : 0; break;
     case POCS_OPT_SUB_BATCHES:
-      if (value < 1 || value > 2) return fail(c, POCS_E_ARG, "sub-batches %lld outside 1..2 (three and four lost: DESIGN.md section 5)", value);
+      if (value < 0 || value > 2) return fail(c, POCS_E_ARG, "sub-batches %lld outside 0..2 (0 = by the call's size; three lost, four gained less than two: DESIGN.md section 5)", value);
       c->opt_groups = value;
       break;
     case POCS_OPT_MC_NONTEMPORAL:
