@@ -626,10 +626,13 @@ def main():
         res["span_timed"] = (not sharded) and span["n"] > 0
         if res["span_timed"]:
             res["avg_ms"] = span["ms"] / span["n"]
-            res["duration_is"] = ("mean launch period inside the replayed graph over every call of the timed region: one pair of hipEvents around "
-                                  "each graph launch, span / launches -- the kernel's duration PLUS the gap to the next launch (an upper bound of "
-                                  "the duration; the rocprofv3 trace under profiles/ has the durations themselves); `bracketed_kernel_us` = "
-                                  "events around every single launch instead, which costs each launch the dispatch it otherwise overlaps")
+            res["duration_is"] = ("mean PERIOD of a waypoint inside the replayed graph over every call of the timed region: one pair of hipEvents "
+                                  "around each graph launch, span / waypoints -- with one launch per waypoint the kernel's duration plus the gap to "
+                                  "the next launch (an upper bound of the duration); with `concurrent_launches` = 2 the call's runs go out as two "
+                                  "launches of half the runs each on two streams, side by side, and the period is that of BOTH: achieved = "
+                                  "algorithmic_bytes_per_period / period, the chip's rate (a profiler's kernel trace shows the half-size launches, each "
+                                  "lasting about a period, and keeps them from overlapping as they do here); `bracketed_kernel_us` = events around "
+                                  "every single launch of sub-batch 0 instead")
         res["groups"], res["waypoint_us"] = groups, waypoint_us
         # sharded through the library's exchange: how long this rank's closers waited for the other ranks' moments in
         # that last call, per (run, waypoint)
@@ -751,8 +754,12 @@ def main():
     bpe = BYTES_PER_EVAL_GMM if path == "gmm" else BYTES_PER_EVAL_MC
     # a call may be issued as G sub-batches whose launches run side by side (POCS_OPT_SUB_BATCHES, default 1): the events
     # bracket sub-batch 0's launches, each of which works on batch / G runs
-    # (span-timed: the period is that of a waypoint of the WHOLE call, all sub-batches side by side, and so are the bytes)
-    units = n_local * batch // (1 if res.get("span_timed") else max(groups, 1))       # evaluations per launch (period)
+    # A call of many runs goes out as G sub-batches on G streams (POCS_OPT_SUB_BATCHES; two by default where the call has
+    # the work for it): G launches of batch / G runs run SIDE BY SIDE, and the span-timed period is that of a waypoint of
+    # the whole call -- so the rate is the chip's: the bytes of all G launches over the period.  (Bracketed timing, the
+    # fallback, times sub-batch 0's launches alone: one launch's bytes over its duration.)
+    per_launch = n_local * batch // max(groups, 1)  # evaluations one launch of the hot kernel processes
+    units = n_local * batch if res.get("span_timed") else per_launch       # ... and one period
     achieved = (bpe * units) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # Committed counter records of this workload (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction applied;
     # profiles/traffic.json with its sources): HBM bytes and vector instructions per launch.  The record nearest in launch
@@ -813,9 +820,10 @@ def main():
                 "traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and avg_ms > 0 and not mc_resident) else None,
                 "copy_GBps": copy_gbps, "frac_of_copy": achieved / copy_gbps if (copy_gbps or 0) > 0 else None,
                 "fill_GBps": fill_gbps, "frac_of_fill": achieved / fill_gbps if (fill_gbps or 0) > 0 else None,
-                "algorithmic_bytes_per_launch": bpe * units, "bytes_per_eval": bpe, "evals_per_launch": units,
+                "algorithmic_bytes_per_launch": bpe * per_launch, "bytes_per_eval": bpe, "evals_per_launch": per_launch,
+                "concurrent_launches": groups, "evals_per_period": units, "algorithmic_bytes_per_period": bpe * units,
                 "avg_kernel_us": avg_ms * 1e3, "duration_is": res["duration_is"], "bracketed_kernel_us": res["bracketed_ms"] * 1e3,
-                "concurrent_launches": groups, "waypoint_us": res["waypoint_us"],
+                "waypoint_us": res["waypoint_us"],
                 "evals_per_s_in_kernel": units / (avg_ms * 1e-3) if avg_ms > 0 else 0.0}
     if path == "mc" and not args.mc_fused:
         roofline["resident"] = "infinity-cache" if mc_resident else "hbm"

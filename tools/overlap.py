@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How the launches of one kernel lie on the time axis, from a rocprofv3 --kernel-trace csv: per launch shape
 the mean duration, and over the whole trace the fraction of the busy span during which 0 / 1 / 2+ launches of
-the kernel were running (tuning aid for the sub-batches of a call, POCS_GMM_GROUPS).
+the kernel were running (the sub-batches of a call, POCS_OPT_SUB_BATCHES).
 usage: overlap.py <dir or kernel_trace.csv> [kernel substring]"""
 import csv
 import sys
