@@ -222,7 +222,8 @@ class BoardProbe:
 
 
 def probe_onehop(par, pocs_amd, torch, dist, rank, world, local):
-    """One small sharded GMM call through the library's IPC exchange (pocs_gmm_sample_exchange_local) on
+    """One small sharded GMM call through the library's IPC exchange -- the whole call in one library call, as the
+    timed runs make it (a connected context's pocs_run_gmm_estimation: graph replay, exchange in the launches' tails) -- on
     this node: True if it ran on every rank and every rank got the same probability.  A node where peer
     mapping or in-kernel peer traffic does not work shows here (an exception, or the kernel's bounded wait
     giving up after 30 s), before anything is timed.  Every rank issues the SAME sequence of collectives
@@ -237,12 +238,13 @@ def probe_onehop(par, pocs_amd, torch, dist, rank, world, local):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t[0].item()), t[1:].tolist()
 
-    ctx, e, mine, ok = None, None, None, True
+    ctx, mine, ok = None, None, True
     try:
         plan, env = pocs_amd.load_plan(), pocs_amd.load_env()
         ctx = pocs_amd.Context(local)
         ctx.configure(plan, env, K=3, N=8192 * world, seed=0x5EED00AA)
-        e = par.GpuEngine(ctx, len(plan["traj"]), 3, 8192 * world, rank=rank, world=world, per_rank=8192, batch=2)
+        ctx.set_batch(2)
+        ctx.set_shard(rank * 8192, 8192)
         mine = ctx.xchg_create(world, rank)
     except Exception as exc:                               # noqa: BLE001
         print("one-hop probe (setup): %s" % exc, file=sys.stderr)
@@ -262,7 +264,7 @@ def probe_onehop(par, pocs_amd, torch, dist, rank, world, local):
     p = -1.0
     if ok:
         try:
-            p = par.run_gmm_onehop_fused([e])[0]
+            p = ctx.run_gmm_estimation()
             torch.cuda.synchronize()
         except Exception as exc:                           # noqa: BLE001 -- whatever it is, the other path is taken
             print("one-hop probe (call): %s" % exc, file=sys.stderr)
@@ -428,10 +430,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # How the shards of the GMM path exchange their moments (POCS_ONEHOP): "2" = the library's one-hop
-    # exchange in the sampling launch's tail (one launch per waypoint, ONE engine, as on one GPU; the
-    # default for N > 1, after a small end-to-end probe of it on this node has succeeded on every rank),
-    # "1" = the one-hop exchange as its own launch, "0" = one RCCL all-reduce per waypoint (two engines).
+    # How the shards of the GMM path exchange their moments (POCS_ONEHOP): "2" = the WHOLE CALL in one library call of a
+    # context connected to its peers -- the same replayed graph and the same two sub-batches as on one GPU, every run's
+    # moments exchanged over one hop in the closing block of its launch, no host in the loop (the default for N > 1,
+    # after a small end-to-end probe of it on this node has succeeded on every rank); "3" = the same exchange with the
+    # launches issued one waypoint at a time from here (pocs_gmm_sample_exchange_local: round 3's default), "1" = the
+    # one-hop exchange as its own launch, "0" = one RCCL all-reduce per waypoint (two engines).
     xstate = {"mode": os.environ.get("POCS_ONEHOP", "2" if (sharded and WORKLOADS[args.workload][3] == "gmm") else "0"),
               "note": None, "probe": None}
     if sharded and xstate["mode"] == "2" and "POCS_ONEHOP" not in os.environ:
@@ -462,7 +466,8 @@ def main():
         # the 256 MB Infinity Cache between two waypoint launches: 8 at 10^6 particles, 64 at 10^5 (cfg5: 0.41 -> 0.75)
         maxb = batch_arg if batch_arg > 0 else (64 if path == "gmm" else max(1, min(64, int(8_000_000 // max(n_local, 1)))))
         ncalls = (steps + maxb - 1) // maxb
-        fused_exchange = xmode == "2"
+        fused_exchange = xmode in ("2", "3")
+        whole = sharded and path == "gmm" and xmode == "2"       # a connected context's whole-run call: the unsharded code path below
         if sharded and path == "gmm" and steps >= 2 and not fused_exchange:
             # N > 1: an even number of calls, so that two engines are always in flight and one engine's
             # all-reduce is covered by the other's kernel
@@ -484,14 +489,16 @@ def main():
                 c.set_option(pocs_amd.OPT_SUB_BATCHES, int(os.environ["POCS_SUB_BATCHES"]))
             if os.environ.get("POCS_NO_GRAPH") == "1":       # diagnostic builds that synchronise inside the launch sequence
                 c.set_option(pocs_amd.OPT_USE_GRAPH, 0)
-            if sharded:     # one rank per GPU: launches on a torch stream, moments in a torch tensor
+            if sharded and not whole:     # one rank per GPU: launches on a torch stream, moments in a torch tensor
                 return c, par.GpuEngine(c, W, K, N, rank=rank, world=world, per_rank=n_local, batch=b, stream=stream)
             c.set_batch(b)
-            c.set_shard(0, n_local)
+            c.set_shard(rank * n_local if whole else 0, n_local)
+            if whole:                     # every rank's exchange buffer mapped by every rank (IPC handles over the host channel)
+                par.connect_contexts(c, dist if world > 1 else None, rank, world)
             return c, None
 
         onehop, run_onehop = False, None
-        if not sharded:
+        if not sharded or whole:
             # one GPU: each distinct batch size has its own context (and its own captured hipGraph)
             made = [make(b_hi, 0x5EED0001)]
             if b_lo != b_hi and b_lo in chunks:
@@ -532,8 +539,8 @@ def main():
             engines = [e for _, e in made]
             # POCS_ONEHOP=1: the library's own exchange (IPC-mapped slots, one hop over xGMI, sum + mixture
             # advance in one small launch) instead of one RCCL all-reduce per waypoint from Python
-            onehop = path == "gmm" and xmode in ("1", "2")
-            run_onehop = par.run_gmm_onehop_fused if xmode == "2" else par.run_gmm_onehop
+            onehop = path == "gmm" and xmode in ("1", "3")
+            run_onehop = par.run_gmm_onehop_fused if xmode == "3" else par.run_gmm_onehop
             if onehop:
                 for e in engines:
                     e.connect_onehop(dist if world > 1 else None, rank, world)
@@ -553,7 +560,7 @@ def main():
                 return p
 
         warm = [b_hi] * max(1, (warmup + batch - 1) // batch) + ([b_lo] if b_lo != b_hi else [])          # >= W untimed steps
-        if sharded and path == "gmm" and xmode in ("1", "2"):
+        if sharded and path == "gmm" and xmode in ("1", "2", "3"):
             # the one-hop exchange has passed a small probe; the warm-up is its first run at full size.  Should it fail
             # there on any rank (the kernel's bounded wait gives up after 30 s and the call returns POCS_E_DEVICE), every
             # rank switches to the RCCL path for the timed region -- agreed by a collective, so that nobody is left behind.
@@ -565,8 +572,13 @@ def main():
                 ok = 0.0
             ok = over_ranks([ok], dist.ReduceOp.MIN if dist is not None else None)[0]
             if not ok:
-                xmode, onehop = "0", False
                 xstate["mode"], xstate["note"] = "0", "one-hop exchange failed in the warm-up at full size: fell back to RCCL"
+                if whole:                                  # (no engines in this form: set the RCCL path up from scratch)
+                    fence()
+                    for c, _ in made:
+                        c.close()
+                    return measure(workload, scaling, steps, warmup, batch_arg, samples, full)
+                xmode, onehop = "0", False
                 run_steps(warm)
         else:
             run_steps(warm)
@@ -584,7 +596,8 @@ def main():
             if dist is not None:
                 d = over_ranks([d], dist.ReduceOp.MAX)[0]
             return d, p
-        if not sharded:
+        plain = not sharded or whole
+        if plain:
             span["ms"], span["n"] = 0.0, 0             # (the warm-up's spans are not the timed region's)
         d0, prob = timed_pass()                        # (`probability` = the last run of the FIRST repeat: reproducible)
         repeats = int(min(200, max(10, math.ceil(TIMED_TARGET_S / max(d0, 1e-6))))) if full else 3
@@ -601,7 +614,7 @@ def main():
 
         # roofline of the dominant kernel: further calls with the hot kernel bracketed by hipEvents on
         # the launch stream (eager launches; not part of `value`)
-        if not sharded:
+        if plain:
             span["on"] = False                             # (the totals of the timed region stay)
         ctx.set_option(pocs_amd.OPT_PROFILE, 1)
         ms_tot, n_launch, groups, waypoint_us = 0.0, 0, 1, None
@@ -623,7 +636,7 @@ def main():
                 waypoint_us = seq_ms * 1e3 / W
         res["bracketed_ms"] = ms_tot / max(n_launch, 1)            # events around every launch (eager)
         res["avg_ms"], res["duration_is"] = res["bracketed_ms"], "hipEvents around every launch of the hot kernel (eager launches), mean"
-        res["span_timed"] = (not sharded) and span["n"] > 0
+        res["span_timed"] = plain and span["n"] > 0
         if res["span_timed"]:
             res["avg_ms"] = span["ms"] / span["n"]
             res["duration_is"] = ("mean PERIOD of a waypoint inside the replayed graph over every call of the timed region: one pair of hipEvents "
@@ -637,7 +650,7 @@ def main():
         # sharded through the library's exchange: how long this rank's closers waited for the other ranks' moments in
         # that last call, per (run, waypoint)
         res["xwait"] = None
-        if engines and onehop and hasattr(ctx.lib, "pocs_get_exchange_wait"):
+        if ((engines and onehop) or whole) and hasattr(ctx.lib, "pocs_get_exchange_wait"):
             try:
                 res["xwait"] = ctx.exchange_wait_us()
             except pocs_amd.PocsError:
@@ -646,7 +659,7 @@ def main():
         # results): what the arithmetic alone takes on this box, to set beside what the stream alone would take at the fill
         # rate -- the two meet at the board's power cap; not part of `value`
         res["nostore_ms"] = None
-        if full and path == "gmm" and not engines and os.environ.get("POCS_NO_STORE") != "1":
+        if full and path == "gmm" and not engines and not whole and os.environ.get("POCS_NO_STORE") != "1":
             if res["span_timed"]:                                # timed the same way as the launches it is set beside
                 ctx.set_option(pocs_amd.OPT_PROFILE, 2)
             ctx.set_option(pocs_amd.OPT_STORE_SAMPLES, 0)
@@ -706,7 +719,8 @@ def main():
     def exchange_text(res):
         if not sharded or res["path"] != "gmm":
             return "none (one GPU)" if not sharded else "none on the data path (MC: one all-reduce of the hit counts per run)"
-        return ("one-hop IPC slots in the sampling launch's tail (pocs_gmm_sample_exchange_local)" if res["xmode"] == "2"
+        return ("one-hop IPC slots in the sampling launches' tails, the whole call replayed from a graph by the library (a connected context's pocs_run_gmm_estimation)" if res["xmode"] == "2"
+                else "one-hop IPC slots in the sampling launch's tail, one launch per waypoint issued from the host (pocs_gmm_sample_exchange_local)" if res["xmode"] == "3"
                 else "one-hop IPC slots (pocs_gmm_exchange_local)" if res["xmode"] == "1"
                 else ("RCCL all-reduce per waypoint" + (" (%s)" % xstate["note"] if xstate["note"] else "")))
 

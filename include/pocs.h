@@ -166,7 +166,17 @@ int pocs_gmm_end(pocs_ctx* ctx, double* probability);
 int pocs_xchg_create(pocs_ctx* ctx, int world, int rank, void* handle64_out);
 int pocs_xchg_connect(pocs_ctx* ctx, const void* handles_world_x_64, int world);
 int pocs_gmm_exchange_local(pocs_ctx* ctx, int waypoint);
-/* The two in ONE launch (what bench.py uses for N > 1 by default, POCS_ONEHOP=2, after a probe of it on the node;
+/* THE WHOLE CALL IN ONE LIBRARY CALL (round 4; what bench.py uses for N > 1 by default, POCS_ONEHOP=2, after a probe of it on
+ * the node): a context that holds a shard (pocs_set_shard) and is connected to its peers (pocs_xchg_create / pocs_xchg_connect),
+ * with no caller-owned moments buffer bound, runs the SHARDED estimation when pocs_run_gmm_estimation (or the text command) is
+ * called on it: the library replays the call from its hipGraph -- the same launches, the same two sub-batches as on one GPU -- and
+ * the block that closes a run's waypoint exchanges the run's moments with the other ranks over one hop, adds them in rank order
+ * and builds the next mixture (as pocs_gmm_sample_exchange_local below does per waypoint).  Every rank returns the same
+ * probabilities; the getters show the whole mixture's moments and states.  The call's number -- part of every row's epoch --
+ * travels in the run headers uploaded per call, so the replayed graph needs no re-capture.  Rules as below: lock step (every
+ * connected rank makes the same calls in the same order), nobody leaves early; a peer that never arrives makes the call return
+ * POCS_E_DEVICE after the kernel's bounded wait.
+ * The same exchange one waypoint at a time, launches issued by the caller (POCS_ONEHOP=3; round 3's default):
  * POCS_ONEHOP=1 is the two-launch form above, POCS_ONEHOP=0 one RCCL all-reduce per waypoint): the block that closes a run's
  * waypoint is also its messenger -- it sends the shard's moments, waits for the world's, adds them in rank
  * order and builds the next mixture, while the launch's finished blocks have already given their CUs to

@@ -475,7 +475,7 @@ void build_run_image(pocs_ctx* c, uint64_t base, double* img) {
   for (int r = R - 1; r >= 0; --r) {          // run 0 last: c->h_chain / h_mu / h_cov keep ITS chain
     const uint64_t seed = effective_seed(c, base + (uint64_t)r);
     compute_chain(c, seed);
-    pocs_run_header hdr; hdr.seed = seed; hdr.pad = 0;
+    pocs_run_header hdr; hdr.seed = seed; hdr.pad = c->xchg_calls;      // (sharded whole calls read their exchange epoch from here)
     memcpy(img + 2 * (size_t)r, &hdr, sizeof hdr);
     memcpy(img + pl.chain + (size_t)r * steps * POCS_CHAIN_STRIDE, c->h_chain.data(), c->h_chain.size() * sizeof(double));
     for (int k = 0; k < c->K; ++k) {
@@ -516,6 +516,7 @@ int stage_and_upload_runs(pocs_ctx* c) {
     build_run_image(c, 0, pin);
   }
   a.valid = false;
+  for (int r = 0; r < R; ++r) ((uint64_t*)pin)[2 * (size_t)r + 1] = c->xchg_calls;      // (the image may have been built a call ago: the headers' exchange count is this call's)
   c->batch_base = c->run_index;
   c->batch_R = R;
   c->view = 0;
@@ -537,6 +538,11 @@ int gmm_upload_run(pocs_ctx* c) {
                              hipMemcpyHostToDevice, c->stream));
   return POCS_OK;
 }
+
+// A whole-run call of a context that is CONNECTED to its peers (pocs_xchg_connect) and holds a shard exchanges every
+// run's moments in the closing block of its launch (k_gmm_step, exchange_in_tail): the call is then the sharded
+// estimation in ONE library call -- the same graph replay, the same two sub-batches as on one GPU, no host in the loop.
+bool whole_call_exchanges(const pocs_ctx* c) { return c->xchg_connected && c->shard_first >= 0 && !c->ext_moments; }
 
 void fill_gmm_launch(pocs_ctx* c, pocs_gmm_launch* a, long long first, long long count, int w,
                      int run_lo = 0, int run_cnt = -1, int groups = 1) {
@@ -580,7 +586,7 @@ int enqueue_advance(pocs_ctx* c, int w) {
 // One run per call (no batch, no run-ahead) on one GPU: the launches close the previous waypoint in their heads
 // (k_gmm_step, "LONE"): 30.6 -> 27.5 us per waypoint at 10^6 samples, K = 3 (MI355X).  POCS_OPT_LONE_CALL = 0
 // keeps the ticket-and-closer form; the results are the same bits.
-bool lone_call(const pocs_ctx* c) { return c->opt_lone && c->batch == 1 && !c->ext_moments; }
+bool lone_call(const pocs_ctx* c) { return c->opt_lone && c->batch == 1 && !c->ext_moments && !(c->xchg_connected && c->shard_first >= 0); }
 void set_lone(pocs_ctx* c, pocs_gmm_launch* a, int w) {
   const size_t half = ((size_t)1 << a->vs_shift) * c->K * POCS_NMOM;      // one run's rows
   a->lone = 1;
@@ -596,6 +602,12 @@ int enqueue_step(pocs_ctx* c, long long first, long long count, int w, bool adva
   fill_gmm_launch(c, &a, first, count, w, run_lo, run_cnt, groups);
   a.advance_in_tail = (advance_in_tail && w + 1 < c->W) ? 1 : 0;
   if (lone) set_lone(c, &a, w);
+  if (whole_call_exchanges(c)) {
+    a.exchange_in_tail = 1;
+    a.xchg_epoch_from_header = 1;
+    for (int q = 0; q < c->xchg_world; ++q) a.xchg.buf[q] = (double*)c->xchg_peer[q];
+    a.xchg.world = c->xchg_world; a.xchg.rank = c->xchg_rank;
+  }
   if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot], stream));
   HIPCHK(c, pocs_launch_gmm_step(c->K, a, stream));
   if (prof_slot >= 0) HIPCHK(c, hipEventRecord(c->events[2 * prof_slot + 1], stream));
@@ -622,7 +634,7 @@ size_t gmm_hot_launches(const pocs_ctx* c) { return (size_t)c->W; }
 // for the same split and left it off: its closers were a third longer and it timed one pass, not a median.)
 // POCS_OPT_SUB_BATCHES: 0 = this rule (default), 1, 2 (tests/test_gpu_parity.py checks the bits).
 int gmm_groups(const pocs_ctx* c) {
-  if (c->ext_moments) return 1;                      // sharded: the caller's exchange covers the whole batch at once
+  if (c->ext_moments) return 1;                      // the caller's all-reduce covers the whole batch at once
   int g = (int)c->opt_groups;
   if (g == 0) {
     const double count = (double)(c->shard_first >= 0 ? c->shard_count : c->num_gmm);
@@ -714,9 +726,9 @@ void gmm_combine(pocs_ctx* c, const double* moments, double* probability) {
 
 std::string config_key(const pocs_ctx* c, long long first, long long count, const char* tag) {
   char buf[256];
-  snprintf(buf, sizeof buf, "%s e%llu W%d K%d R%d g%d l%d n%lld f%lld c%lld s%lld fu%lld st%p em%p", tag, c->epoch,
-           c->W, c->K, c->batch, gmm_groups(c), lone_call(c) ? 1 : 0, c->num_gmm, first, count, c->opt_store, c->opt_fused,
-           (void*)c->stream, (void*)c->ext_moments);
+  snprintf(buf, sizeof buf, "%s e%llu W%d K%d R%d g%d l%d x%d n%lld f%lld c%lld s%lld fu%lld st%p em%p", tag, c->epoch,
+           c->W, c->K, c->batch, gmm_groups(c), lone_call(c) ? 1 : 0, (c->xchg_connected && c->shard_first >= 0 && !c->ext_moments) ? c->xchg_world : 0,
+           c->num_gmm, first, count, c->opt_store, c->opt_fused, (void*)c->stream, (void*)c->ext_moments);
   return buf;
 }
 
@@ -733,6 +745,10 @@ int run_gmm_full(pocs_ctx* c, double* probability) {
   long long first, count;
   if (int r = gmm_shard(c, &first, &count)) return r;
   lap("prepared");
+  if (whole_call_exchanges(c)) {
+    if (c->batch > POCS_XCHG_MAX_RUNS) return fail(c, POCS_E_ARG, "exchange: at most %d runs per call", POCS_XCHG_MAX_RUNS);
+    c->xchg_calls += 1;                                // one exchange sequence: every connected rank makes the same calls in the same order
+  }
   if (int r = gmm_upload_run(c)) return r;
   lap("upload enqueued");
   // POCS_OPT_PROFILE: 1 = events around every launch of the hot kernel (eager launches: an event between two kernels

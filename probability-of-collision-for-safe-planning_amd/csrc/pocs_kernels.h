@@ -48,7 +48,7 @@ struct pocs_env_dev {            // collision world as the kernels see it (one c
 
 struct pocs_run_header {         // per-run scalars read by every kernel (so a captured graph stays valid)
   uint64_t seed;
-  uint64_t pad;
+  uint64_t pad;                  // sharded whole calls: the context's count of exchange sequences (pocs_gmm_launch::xchg_epoch_from_header)
 };
 
 // One-hop exchange of the per-waypoint moments between the GPUs of a node: every rank
@@ -102,6 +102,7 @@ struct pocs_gmm_launch {
   int store;
   int advance_in_tail;           // 1: the last block also builds state/param[waypoint+1] (single GPU)
   int exchange_in_tail;          // 1: ... after exchanging the run's moments with the other ranks through `xchg` (sharded)
+  int xchg_epoch_from_header;    // 1: the exchange's call number comes from hdr[run].pad (whole calls replayed from a graph), not from xchg
   int lone;                      // 1: one run per call -- no tickets, no closer: every block of waypoint w's launch adds the
                                  //    rows of w-1 and advances the mixture itself, in its head (k_gmm_step, "lone call")
   pocs_xchg_dev xchg;

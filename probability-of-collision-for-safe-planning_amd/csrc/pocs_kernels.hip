@@ -981,7 +981,15 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
       // come back summed in rank order, and the mixture advances here (no launch, no host, between waypoints)
       __syncthreads();
       if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-      if (!gmm_exchange_rows(a, a.xchg, K, w, r, l_mom, l_mom, tid, TB, &sm.nkeep[0] /* free by now */)) return false;
+      // (a whole call replayed from a graph bakes its arguments in: the call's number -- part of every row's epoch and
+      // of the choice between the two slot sets -- then travels in the run's header, uploaded per call like its seed)
+      pocs_xchg_dev x = a.xchg;
+      if (a.xchg_epoch_from_header) {
+        const unsigned long long calls = a.hdr[r].pad;
+        x.epoch = (calls << 20) | (unsigned long long)(w + 1);
+        x.parity = (int)((calls * (unsigned long long)a.W + (unsigned long long)w) & 1ull);
+      }
+      if (!gmm_exchange_rows(a, x, K, w, r, l_mom, l_mom, tid, TB, &sm.nkeep[0] /* free by now */)) return false;
     }
     if (a.advance_in_tail) advance_block(a, K, w + 1, r, sm.adv(), sm.spec(), true, tid, TB);     // starts with a barrier after staging
     __syncthreads();

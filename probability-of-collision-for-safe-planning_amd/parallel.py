@@ -130,6 +130,21 @@ def run_gmm_pipelined(engines, dist):
     return out
 
 
+def connect_contexts(ctx, dist, rank, world):
+    """A context with a shard set (pocs_set_shard) joins its peers: every rank creates its exchange buffer, the 64-byte IPC
+    handles go round once over the host channel of the process group, every rank maps every buffer.  From then on
+    ctx.run_gmm_estimation() IS the sharded estimation: the library replays the whole call from a graph -- the same two
+    sub-batches as on one GPU -- and every run's moments cross the ranks over one hop in the closing block of its launch;
+    every rank returns the same probabilities.  Connected contexts make the same calls in the same order (include/pocs.h)."""
+    mine = ctx.xchg_create(world, rank)
+    if dist is not None and world > 1:
+        handles = [None] * world
+        dist.all_gather_object(handles, mine)
+    else:
+        handles = [mine]
+    ctx.xchg_connect(handles)
+
+
 def run_mc_sharded(engine, n_total, dist=None):
     """engine: mc_local() -> int64 tensor with the shard's collided count of every run of the
     batch.  Returns run 0's probability (all of them: engine.last_mc_probabilities)."""

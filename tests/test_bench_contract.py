@@ -115,6 +115,7 @@ def test_gpus_2_started_by_hand_brings_up_its_own_ranks():
     d = run_bench("--gpus", "2", "--no-cpu-baseline", env=dict(env, POCS_FORCE_DEVICE="0", POCS_DIST_BACKEND="gloo",
                                                                 POCS_SKIP_SINGLE="1", POCS_NO_BOARD_PROBE="1"))
     assert d["n_gpus"] == 2 and d["config"]["total_samples_per_run"] == 40000 and "tail" in d["config"]["exchange"]
+    assert "whole call" in d["config"]["exchange"]                # ... replayed from a graph by the library, as on one GPU
     assert len(d["roofline"]["ranks_kernel_us"]["all"]) == 2
     # a scaling run that explains itself: the probe's outcome and time, the closers' waits for the other rank's moments
     # (in-kernel clock), the ranks' kernel times and their spread -- and the strong-scaling workload riding along

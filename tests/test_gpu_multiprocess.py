@@ -78,6 +78,30 @@ def _worker_onehop(rank, world, port, n_local, K, seed, batch, out):
         res[mode] = (list(e.probabilities()), np.array([c.moments(w, K) for w in range(56)]))
         dist.barrier()
         c.close()
+    # the WHOLE CALL in one library call (what bench.py --gpus N uses since round 4): a context with its shard set, connected
+    # to its peers, replays the call from a graph and exchanges every run's moments in the closing block of its launch --
+    # as one launch per waypoint, as two sub-batches on two streams, and a second call on the same buffers (the call's
+    # number travels in the run headers: a replayed graph bakes its arguments in)
+    c = pocs_amd.Context(0)
+    c.configure(plan, env, K=K, N=N, seed=seed)
+    c.set_batch(batch)
+    c.set_shard(rank * n_local, n_local)
+    par.connect_contexts(c, dist, rank, world)
+    whole = {}
+    for tag, groups in (("one", 1), ("sub2", 2), ("again", 0)):
+        c.set_option(pocs_amd.OPT_SUB_BATCHES, groups)
+        c.set_seed(seed)
+        c.run_gmm_estimation()
+        torch.cuda.synchronize()
+        whole[tag] = (list(c.batch_probabilities()), np.array([c.moments(w, K) for w in range(56)]))
+        dist.barrier()
+    c.run_gmm_estimation()                                # (no rewind: the next runs of the context)
+    torch.cuda.synchronize()
+    whole["next"] = (list(c.batch_probabilities()), None)
+    wait_us = c.exchange_wait_us()
+    assert 0.0 <= wait_us[0] <= wait_us[1] <= wait_us[2] < 5e6
+    dist.barrier()
+    c.close()
     # skew tolerance: TWO engines (two batches of runs, two streams, two exchange buffers) in flight through the in-tail
     # exchange, against the same two batches through the collective
     pair = {}
@@ -123,6 +147,8 @@ def _worker_onehop(rank, world, port, n_local, K, seed, batch, out):
     if rank == 0:
         np.savez(out, p_gloo=res["gloo"][0], p_one=res["onehop"][0], m_gloo=res["gloo"][1], m_one=res["onehop"][1],
                  p_again=res["onehop_again"][0], p_fused=res["fused"][0], m_fused=res["fused"][1],
+                 p_whole=whole["one"][0], m_whole=whole["one"][1], p_whole2=whole["sub2"][0], m_whole2=whole["sub2"][1],
+                 p_whole3=whole["again"][0], p_whole_next=whole["next"][0],
                  odd_gloo=res["gloo_odd"], odd_fused=res["fused_odd"], odd_onehop=res["onehop_odd"],
                  two_gloo=res["gloo2"], two_fused=res["fused2"])
     dist.destroy_process_group()
@@ -143,6 +169,12 @@ def test_onehop_exchange_equals_the_collective(tmp_path, pocs, plan, env):
     assert list(got["p_again"]) != list(got["p_one"]) and all(0 < p < 1 for p in got["p_again"])
     # the exchange in the sampling launch's tail: the same bits again
     assert list(got["p_fused"]) == list(got["p_gloo"]) and np.array_equal(got["m_fused"], got["m_gloo"])
+    # the whole call in one library call (graph replay, exchange in the tails): the same bits -- one launch per waypoint, two
+    # sub-batches, a third call after a rewind; and the call after that redraws
+    assert list(got["p_whole"]) == list(got["p_gloo"]) and np.array_equal(got["m_whole"], got["m_gloo"])
+    assert list(got["p_whole2"]) == list(got["p_gloo"]) and np.array_equal(got["m_whole2"], got["m_gloo"])
+    assert list(got["p_whole3"]) == list(got["p_gloo"])
+    assert list(got["p_whole_next"]) != list(got["p_gloo"]) and all(0 < p < 1 for p in got["p_whole_next"])
     # 21 waypoints, three calls in a row on the same buffers: every call of both one-hop forms equals the collective's
     assert list(got["odd_fused"]) == list(got["odd_gloo"]) and list(got["odd_onehop"]) == list(got["odd_gloo"])
     assert len(set(got["odd_gloo"])) == len(got["odd_gloo"])
