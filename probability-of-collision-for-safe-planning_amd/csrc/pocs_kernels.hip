@@ -382,9 +382,10 @@ __device__ __forceinline__ unsigned long long* xchg_flag(double* buf, int parity
 // The exchange itself, by the `nthreads` threads of one block for run r at waypoint w: `mine` (NC doubles,
 // global or LDS) -> slot `rank` of every rank's buffer; wait for the world's rows; the sum in rank order
 // -> a.moments[w][r] and l_mom (LDS; may be `mine`).  s_ok: one int of LDS.  false = gave up.
-__device__ __forceinline__ bool gmm_exchange_rows(const pocs_gmm_launch& a, const pocs_xchg_dev& x, const int K, const int w, const int r,
+__device__ __forceinline__ bool gmm_exchange_rows(const pocs_gmm_launch& a, const pocs_xchg_dev& x, const unsigned long long epoch, const int parity,
+                                                  const int K, const int w, const int r,
                                                   const double* mine, double* l_mom, const int tid, const int nthreads, int* s_ok) {
-  const int NC = K * POCS_NMOM, parity = x.parity;
+  const int NC = K * POCS_NMOM;
   for (int i = tid; i < NC * x.world; i += nthreads) {
     const int q = i / NC, c = i - q * NC;
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(xchg_row(x.buf[q], parity, x.rank, r) + c),
@@ -397,7 +398,7 @@ __device__ __forceinline__ bool gmm_exchange_rows(const pocs_gmm_launch& a, cons
   drain_stores();
   __syncthreads();
   if (tid < x.world)
-    __hip_atomic_store(xchg_flag(x.buf[tid], parity, x.rank, r), x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(xchg_flag(x.buf[tid], parity, x.rank, r), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // every rank's row of this waypoint has landed in MY buffer?
   if (tid == 0) *s_ok = 1;
   __syncthreads();
@@ -405,7 +406,7 @@ __device__ __forceinline__ bool gmm_exchange_rows(const pocs_gmm_launch& a, cons
     const unsigned long long* f = xchg_flag(x.buf[x.rank], parity, tid, r);
     const unsigned long long t0 = wall_clock64();
     unsigned polls = 0;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != x.epoch) {
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
       __builtin_amdgcn_s_sleep(8);
       if ((++polls & 255u) == 0u && wall_clock64() - t0 > 3000000000ull) {      // 30 s: ranks of a cold node start seconds apart
         __hip_atomic_store(&a.sync[POCS_SYNC_ABORT], 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(128) void k_gmm_exchange(pocs_gmm_launch a, pocs_xc
   // an earlier exchange of this call gave up: do not wait another 30 s per waypoint, the call is lost
   if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   double* const l_mom = advance_ptrs(a, K, w + 1, r, s_adv).l_mom;
-  if (!gmm_exchange_rows(a, x, K, w, r, a.moments + ((size_t)w * a.nruns + r) * NC, l_mom, tid, 128, &s_ok)) return;
+  if (!gmm_exchange_rows(a, x, x.epoch, x.parity, K, w, r, a.moments + ((size_t)w * a.nruns + r) * NC, l_mom, tid, 128, &s_ok)) return;
   if (w + 1 < a.W) advance_block(a, K, w + 1, r, s_adv, s_spec, true, tid, 128);     // starts with a barrier after staging
 }
 
@@ -983,13 +984,14 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
       if (__hip_atomic_load(&a.sync[POCS_SYNC_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
       // (a whole call replayed from a graph bakes its arguments in: the call's number -- part of every row's epoch and
       // of the choice between the two slot sets -- then travels in the run's header, uploaded per call like its seed)
-      pocs_xchg_dev x = a.xchg;
+      unsigned long long epoch = a.xchg.epoch;
+      int parity = a.xchg.parity;
       if (a.xchg_epoch_from_header) {
         const unsigned long long calls = a.hdr[r].pad;
-        x.epoch = (calls << 20) | (unsigned long long)(w + 1);
-        x.parity = (int)((calls * (unsigned long long)a.W + (unsigned long long)w) & 1ull);
+        epoch = (calls << 20) | (unsigned long long)(w + 1);
+        parity = (int)((calls * (unsigned long long)a.W + (unsigned long long)w) & 1ull);
       }
-      if (!gmm_exchange_rows(a, x, K, w, r, l_mom, l_mom, tid, TB, &sm.nkeep[0] /* free by now */)) return false;
+      if (!gmm_exchange_rows(a, a.xchg, epoch, parity, K, w, r, l_mom, l_mom, tid, TB, &sm.nkeep[0] /* free by now */)) return false;
     }
     if (a.advance_in_tail) advance_block(a, K, w + 1, r, sm.adv(), sm.spec(), true, tid, TB);     // starts with a barrier after staging
     __syncthreads();
