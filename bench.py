@@ -34,7 +34,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-NUMERICS = "v8"                 # counter records of another numerics version describe another kernel
+NUMERICS = "v9"                 # counter records of another numerics version describe another kernel
 BYTES_PER_EVAL_GMM = 26         # 3 x f64 sample + i16 flag streamed out once
 BYTES_PER_EVAL_MC = 56          # 24 B in + 24 B out + u32 hit counter read + write
 CPU_BUDGET_FACTOR = 3           # the CPU baseline may take this many times the wall time of the run's GPU part

@@ -54,7 +54,7 @@
 #define ORC_STATE 16
 
 /* ------------------------------------------------------------------------------------------ */
-/* random streams (build spec "POCS numerics v8")                          */
+/* random streams (build spec "POCS numerics v9")                          */
 /* ------------------------------------------------------------------------------------------ */
 void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
   uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
@@ -193,9 +193,10 @@ void orc_normal3(uint64_t seed, uint64_t index, uint32_t waypoint, uint32_t stre
   *spare = a[3];
 }
 
-/* ---- table-driven forms (hot path: mixture samples, footprint heading), numerics v8 ------------
- * lg[i] = {1/c_i rounded, 2 log(that)}, c_i = 1 + (i + 1/2)/512; sc[s] = {cos, sin} of 2 pi s / 256, the
- * sector boundaries.  Built from the functions above, on first use. */
+/* ---- table-driven forms (hot path: mixture samples, footprint heading), numerics v9 ------------
+ * lg[i] = {1/c_i rounded, 2 log(that) + 2 ln 2}, c_i = 1 + (i + 1/2)/512; sc[s] = {cos, sin} of 2 pi s / 256,
+ * the sector boundaries.  Built from the functions above, on first use. */
+static const double TWO_LN2 = 1.386294361119890572454e+00;
 static double tab_lg[512][2], tab_sc[256][2];
 static int tab_ready = 0;
 static void tables(void) {
@@ -203,7 +204,7 @@ static void tables(void) {
   for (int i = 0; i < 512; ++i) {
     double c = 1.0 + ((double)i + 0.5) / 512.0;
     tab_lg[i][0] = 1.0 / c;
-    tab_lg[i][1] = 2.0 * orc_log(tab_lg[i][0]);
+    tab_lg[i][1] = 2.0 * orc_log(tab_lg[i][0]) + TWO_LN2;
   }
   for (int s = 0; s < 256; ++s) {
     double sn, cs;
@@ -213,44 +214,60 @@ static void tables(void) {
   tab_ready = 1;
 }
 
-/* -2 log((w + 1) 2^-32), the squared Box-Muller radius of a uniform on (0, 1] with 2^32 levels:
- * w + 1 = 2^e t; cell i of t; r = t / c_i - 1; -2 log t = 2 log(1/c_i) - 2 log1p(r), the latter as the
- * degree-4 polynomial r (-2 + r (1 + r (-2/3 + r/2))); plus (e - 32) (-2 ln 2), one rounded product. */
+/* -2 log(w 2^-32), the squared Box-Muller radius of a uniform with the levels 0, 2^-32, ..., 1 - 2^-32:
+ * w = 2^e t, e = 31 - (leading zeros z of w); cell i of t; r = t / c_i - 1; -2 log t = 2 log(1/c_i) - 2 log1p(r),
+ * the latter as r times the cubic (-2 + r (1 + r (-2/3 + r/2))); the exponent's share is (z + 1) 2 ln 2, whose
+ * "+ 1" sits in the table entry: z 2 ln 2 is added to the entry in one fma, the polynomial in a second.  The level
+ * 0 has no logarithm: the build spec gives it the value of cell 0 with r = -1 and z = -1 (4.1647: a radius of 2.04). */
 double orc_radius2_unit32(uint32_t w) {
   tables();
-  double x = (double)w + 1.0;
-  uint64_t bits;
-  memcpy(&bits, &x, 8);
-  int e = (int)(bits >> 52) - 1023;
-  int i = (int)((bits >> 43) & 511);
-  bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
-  double t;
-  memcpy(&t, &bits, 8);
-  double r = fma(t, tab_lg[i][0], -1.0);
+  double r, base;
+  int z;
+  if (w == 0) {
+    r = -1.0; base = tab_lg[0][1]; z = -1;
+  } else {
+    double x = (double)w;
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int e = (int)(bits >> 52) - 1023;
+    int i = (int)((bits >> 43) & 511);
+    bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double t;
+    memcpy(&t, &bits, 8);
+    r = fma(t, tab_lg[i][0], -1.0);
+    base = tab_lg[i][1];
+    z = 31 - e;
+  }
   static const double co[4] = {-2.0, 1.0, -2.0 / 3.0, 0.5};
   double p = co[3];
   for (int k = 2; k >= 0; --k) p = fma(r, p, co[k]);
-  double small = tab_lg[i][1] + r * p;
-  return fma((double)(e - 32), -1.386294361119890572454e+00, small);
+  return fma(r, p, fma((double)z, TWO_LN2, base));
 }
 
+/* |d| <= pi/256 in radians: sine to d^5; cosine 1 - d^2/2 + C4 d^4 with the build spec's fitted C4 (the
+ * coefficient of least maximum error on the interval, 5.0e-16; tools/make_v9_constants.py) */
+static const double COS_C4 = 4.166647965169937434249e-02;
 static void sincos_small(double d, double* sd, double* cd) {
   double z = d * d;
-  double ps = fma(z, 1.0 / 120.0, -1.0 / 6.0);           /* |d| <= pi/256: next terms < 1e-17 */
+  double ps = fma(z, 1.0 / 120.0, -1.0 / 6.0);
   *sd = fma(d * z, ps, d);
-  double pc = fma(z, -1.0 / 720.0, 1.0 / 24.0);
-  pc = fma(z, pc, -0.5);
-  *cd = fma(z, pc, 1.0);
+  *cd = fma(z, fma(z, COS_C4, -0.5), 1.0);
 }
 
-/* the Box-Muller angle of a word: table entry of its top 8 bits, the low 24 bits a signed offset from it */
+/* the Box-Muller angle of a word: table entry of its top 8 bits, the low 24 bits READ AS A SIGNED (two's
+ * complement) number k in [-2^23, 2^23) an offset from it -- a one-to-one map of words to the 2^32 angles --;
+ * the same two polynomials in k instead of d = k a, a = 2 pi 2^-32, their coefficients scaled by powers of a */
 void orc_sincos_2pi_u32_tab(uint32_t w, double* s, double* c) {
+  static const double S1 = 1.462918079267159624024e-09, S3 = -5.218056424438286096208e-28,
+                      S5 = 5.583657738838274755966e-47, C2 = -1.070064653323357779997e-18,
+                      C4 = 1.908388704914255060734e-37;
   tables();
   int sec = (int)(w >> 24);
-  int f = (int)(w & 0x00ffffffu) - (1 << 23);
-  double d = (double)f * ((1.0 / 16777216.0) * 2.45436926061702587187e-02);   /* 2 pi / 256 */
-  double sd, cd;
-  sincos_small(d, &sd, &cd);
+  int low = (int)(w & 0x00ffffffu);
+  double k = (double)(low >= (1 << 23) ? low - (1 << 24) : low);
+  double z = k * k;
+  double sd = k * fma(z, fma(z, S5, S3), S1);
+  double cd = fma(z, fma(z, C4, C2), 1.0);
   double C = tab_sc[sec][0], S = tab_sc[sec][1];
   *s = fma(S, cd, C * sd);
   *c = fma(C, cd, -(S * sd));
@@ -260,8 +277,7 @@ void orc_sincos_tab(double x, double* s, double* c) {
   tables();
   double fn = rint(x * 4.07436654315252084757e+01);       /* 256 / (2 pi) */
   int n = (int)fn;
-  double d = fma(-fn, 2.45436926052207127213e-02, x);     /* pi/128 = its first 34 bits + the rest */
-  d = fma(-fn, 9.495469541415925389561e-13, d);
+  double d = fma(-fn, 2.45436926061702587187e-02, x);     /* pi/128 rounded: one step */
   double sd, cd;
   sincos_small(d, &sd, &cd);
   int sec = n & 255;
@@ -272,7 +288,7 @@ void orc_sincos_tab(double x, double* s, double* c) {
 
 /* Box-Muller pair of the mixture sampler: radius word wr, angle word wa. */
 void orc_normal_pair_w2(uint32_t wr, uint32_t wa, double* n0, double* n1) {
-  double radius = sqrt(fabs(orc_radius2_unit32(wr)));      /* |.|: at u = 1 the value is a rounding error around 0 */
+  double radius = sqrt(fabs(orc_radius2_unit32(wr)));
   double s, c;
   orc_sincos_2pi_u32_tab(wa, &s, &c);
   *n0 = radius * c;

@@ -25,7 +25,7 @@
 #include "pocs_kernels.h"
 #include "pocs_command.hpp"
 
-#define POCS_VERSION_STRING "pocs-mi355x 0.4 (gfx950; numerics v8: summation tree of 512-pair chunks, 256 virtual slices)"
+#define POCS_VERSION_STRING "pocs-mi355x 0.4 (gfx950; numerics v9: summation tree of 512-pair chunks, 256 virtual slices)"
 
 namespace {
 

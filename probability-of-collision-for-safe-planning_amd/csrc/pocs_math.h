@@ -6,7 +6,7 @@
 //     is an explicit fma();
 //   * only +, -, *, /, sqrt, fma, rint and integer ops are used (all correctly rounded on
 //     both sides), never a vendor libm transcendental.
-// The spec ("POCS numerics v8") is written out in DESIGN.md section 4; the CPU oracle under
+// The spec ("POCS numerics v9") is written out in DESIGN.md section 4; the CPU oracle under
 // oracle/ holds an independent plain-C restatement of the same spec and is never linked here.
 //
 // What this replaces in the reference: Armadillo's RNG + mvnrnd (GM_Model.h:83-116,
@@ -182,28 +182,43 @@ POCS_HD void pocs_normal_pair(uint32_t w0, uint32_t w1, uint32_t w2, double* n0,
 // Table-driven forms used on the hot path (mixture samples, footprint heading): less than half the
 // instructions of the polynomial forms above.  The 12 KB of tables are built once on the host FROM THE
 // FUNCTIONS ABOVE (so product and oracle, whose functions agree bit for bit, build identical tables) and
-// staged in LDS by the kernels.  Numerics v8:
-//   lg[i] = {invc_i, 2 log(invc_i)},  c_i = 1 + (i + 1/2)/512,  invc_i = 1/c_i rounded
-//   sc[s] = {cos, sin} of 2 pi s / 256: the sector BOUNDARIES (v7 held the centres: the heading then paid
-//           half a sector's shift per evaluation; for the Box-Muller angle a fixed rotation is no change of law)
+// staged in LDS by the kernels.  Numerics v9 (tables as in v8):
+//   lg[i] = {invc_i, 2 log(invc_i) + 2 ln 2},  c_i = 1 + (i + 1/2)/512,  invc_i = 1/c_i rounded
+//   sc[s] = {cos, sin} of 2 pi s / 256: the sector BOUNDARIES
 // ----------------------------------------------------------------------------------------
 struct pocs_tables {
   double lg[512][2];
   double sc[256][2];
 };
 
-// The first Horner step of the sine and cosine polynomials below multiplies by one literal and adds another; a
-// gfx950 VALU instruction reads at most one literal / scalar operand, so one of the two needs a register and
-// the compiler materialises it with a v_mov_b64 EVERY time.  The hot kernel keeps the two addends in vector
+// Polynomial constants of the forms below (v9).  BM_*: sine and cosine of the Box-Muller angle IN UNITS OF THE
+// WORD'S LOW 24 BITS read as a signed number, k in [-2^23, 2^23) an exact integer, angle d = k a with a = 2 pi 2^-32:
+//   sin d = k (a - a^3/6 k^2 + a^5/120 k^4),   cos d = 1 - a^2/2 k^2 + C4 a^4 k^4
+// (v8 multiplied k by a first and ran the polynomials in d: one product more per angle).  C4 is not 1/24: the cosine
+// stops at d^4 (v8: d^6) and C4 is the coefficient that minimises the largest error of 1 - d^2/2 + C4 d^4 over
+// |d| <= pi/256 with the first two coefficients held at the instruction set's inline constants 1 and -1/2:
+// 5.0e-16 at most (Taylor's 1/24: 4.7e-15; computed with 60 digits, tools/make_v9_constants.py).  The sine
+// keeps d^5: truncation 8.3e-18.
+#define POCS_BM_S1 1.462918079267159624024e-09    /* a             0x1.921fb54442d18p-30 */
+#define POCS_BM_S3 -5.218056424438286096208e-28   /* -a^3 / 6      -0x1.4abbce625be53p-91 */
+#define POCS_BM_S5 5.583657738838274755966e-47    /* a^5 / 120     0x1.466bc6775aae2p-154 */
+#define POCS_BM_C2 -1.070064653323357779997e-18   /* -a^2 / 2      -0x1.3bd3cc9be45dep-60 */
+#define POCS_BM_C4 1.908388704914255060734e-37    /* C4 a^4        0x1.03c1a4196664ep-122 */
+#define POCS_COS_C4 4.166647965169937434249e-02   /* C4            0x1.5554f0ee31235p-5 */
+#define POCS_2LN2 1.386294361119890572454e+00
+
+// The first Horner step of each polynomial multiplies by one constant and adds another; a gfx950 VALU instruction
+// reads at most one literal / scalar operand, so one of the two needs a register and the compiler materialises it
+// with a v_mov_b64 EVERY time.  The hot kernel keeps the three addends that are not inline constants in vector
 // registers for the length of its loop instead (POCS_VCONST pins them there); same values, same operations.
-// Everyone else passes nullptr and gets the literals.  (The radius polynomial of v8 needs none: its addends
-// are inline constants of the instruction set.)
-struct pocs_vconst { double sin_c3, cos_c4; };    // -1/6, 1/24
+// Everyone else passes nullptr and gets the literals.  (The radius polynomial and the heading's cosine need none:
+// their addends are inline constants of the instruction set.)
+struct pocs_vconst { double bm_s3, bm_c2, sin_c3; };
 #if defined(__HIP_DEVICE_COMPILE__)
-#define POCS_VCONST(name) pocs_vconst name = {-1.0 / 6.0, 1.0 / 24.0}; \
-  asm volatile("" : "+v"(name.sin_c3), "+v"(name.cos_c4))
+#define POCS_VCONST(name) pocs_vconst name = {POCS_BM_S3, POCS_BM_C2, -1.0 / 6.0}; \
+  asm volatile("" : "+v"(name.bm_s3), "+v"(name.bm_c2), "+v"(name.sin_c3))
 #else
-#define POCS_VCONST(name) pocs_vconst name = {-1.0 / 6.0, 1.0 / 24.0}
+#define POCS_VCONST(name) pocs_vconst name = {POCS_BM_S3, POCS_BM_C2, -1.0 / 6.0}
 #endif
 
 POCS_HD void pocs_tables_init(pocs_tables* T) {
@@ -211,7 +226,7 @@ POCS_HD void pocs_tables_init(pocs_tables* T) {
     const double c = 1.0 + ((double)i + 0.5) * 0x1p-9;
     const double invc = 1.0 / c;
     T->lg[i][0] = invc;
-    T->lg[i][1] = 2.0 * pocs_log(invc);
+    T->lg[i][1] = 2.0 * pocs_log(invc) + POCS_2LN2;
   }
   for (int s = 0; s < 256; ++s) {
     double sn, cs;
@@ -221,75 +236,92 @@ POCS_HD void pocs_tables_init(pocs_tables* T) {
   }
 }
 
-// The squared Box-Muller radius -2 log((w + 1) 2^-32) of a 32-bit word w, i.e. of a uniform on (0, 1] with
-// 2^32 levels, in ONE pass (v7 took the logarithm, then doubled it):
-//   m = w + 1 = 2^e t, t in [1, 2); i = top 9 mantissa bits; r = t invc_i - 1 (one fma, |r| <= 2^-10);
+// The squared Box-Muller radius -2 log(w 2^-32) of a 32-bit word w, i.e. of a uniform with the 2^32 levels
+// 0, 2^-32, ..., 1 - 2^-32, in ONE pass:
+//   w = 2^e t, t in [1, 2), e = 31 - z with z the number of leading zero bits of w; i = top 9 mantissa bits;
+//   r = t invc_i - 1 (one fma, |r| <= 2^-10);
 //   -2 log t = 2 log(invc_i) - 2 log1p(r),   -2 log1p(r) = r (-2 + r (1 + r (-2/3 + r/2)))   (truncation < 4e-16);
-//   result = fma(e - 32, -2 ln 2, 2 log(invc_i) - 2 log1p(r)):
-// one product with ln 2, not a high and a low one -- the result is rounded once at its own magnitude, and where it
-// cancels (u near 1: e = 31, the table entry near -2 ln 2) a few 1e-16 of absolute error are six orders below the
-// 4.7e-10 between two neighbouring levels of the word.  Absolute error <= 1e-15 over all 2^32 words (CPU tests).
+//   -2 log(2^(e-32)) = (z + 1) 2 ln 2, the "+ 1" of which the table entry already holds:
+//   result = fma(r, p(r), fma(z, 2 ln 2, lg[i][1]))
+// (v8: the word + 1, the exponent out of frexp, the three terms added in two steps and an fma: one addition, one
+// subtraction and one product more).  The inner fma is rounded once at its own magnitude: where its terms are small
+// (u near 1: z = 0, the table entry 2 log(2 invc_i) itself, near 0) it carries the 1e-16 of the entry, six orders below
+// the 4.7e-10 between two neighbouring levels.  Absolute error <= 1e-15 over all words (CPU tests).
+// THE LEVEL 0 (one word in 2^32) has no logarithm; it is given the value the same instructions produce from what the
+// hardware returns for a zero word -- mantissa 0, hence cell 0 and r = -1; z = -1 (v_ffbh_u32 finds no bit) --:
+// 25/6 + 2 log(invc_0) = 4.1647, a radius of 2.0408: finite and nowhere near the bound the obstacle culling of
+// k_gmm_step works with, which the level 2^-32 sets: sqrt(64 ln 2) < 6.661.  The other end, u = 1 - 2^-32: 4.66e-10.
 POCS_HD double pocs_radius2_unit32(uint32_t w, const pocs_tables* T) {
-  union { double d; uint64_t u; } b; b.d = (double)w + 1.0;      // exact: m <= 2^32
 #if defined(__HIP_DEVICE_COMPILE__)
-  // The same quantities with fewer instructions.  m = 2^e t = 2^(e+1) mant with mant = t / 2 in [1/2, 1): the
-  // hardware's frexp gives mant and e + 1 in one instruction each; the table entry's byte offset is a shift
-  // and a mask of the high word; and r = fma(t, invc, -1) = fma(mant, 2 invc, -1) exactly, for which the
-  // kernel's LDS copy of the table holds 2 invc (stage_tables doubles the entry on its way in: exact).
-  const int e1 = __builtin_amdgcn_frexp_exp(b.d);                 // e + 1
-  const double mant = __builtin_amdgcn_frexp_mant(b.d);
+  // w = 2^(e+1) mant with mant = t / 2 in [1/2, 1): the hardware's frexp gives mant in one instruction; the table
+  // entry's byte offset is a shift and a mask of the high word; and r = fma(t, invc, -1) = fma(mant, 2 invc, -1)
+  // exactly, for which the kernel's LDS copy of the table holds 2 invc (stage_tables doubles the entry on its way
+  // in: exact).  The leading zeros: v_ffbh_u32, which returns -1 for a zero word (__builtin_clz leaves that open).
+  union { double d; uint64_t u; } b; b.d = (double)w;
+  int lz;
+  asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(w));
+  const double mant = __builtin_amdgcn_frexp_mant(b.d);           // (0 for w = 0)
   const unsigned off = ((unsigned)(b.u >> 32) >> 7) & 0x1ff0u;    // 16 i
   const double* ent = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&T->lg[0][0]) + off);
   const double r = fma(mant, ent[0], -1.0);
   const double l2c = ent[1];
-  const double dk = (double)(e1 - 33);
 #else
-  const int e = (int)(b.u >> 52) - 1023;
-  const int i = (int)(b.u >> 43) & 511;
-  b.u = (b.u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;   // t
-  const double r = fma(b.d, T->lg[i][0], -1.0);
-  const double l2c = T->lg[i][1];
-  const double dk = (double)(e - 32);
+  double r, l2c;
+  int lz;
+  if (w == 0u) {
+    r = -1.0; l2c = T->lg[0][1]; lz = -1;
+  } else {
+    union { double d; uint64_t u; } b; b.d = (double)w;
+    const int i = (int)(b.u >> 43) & 511;
+    b.u = (b.u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;   // t
+    r = fma(b.d, T->lg[i][0], -1.0);
+    l2c = T->lg[i][1];
+    lz = __builtin_clz(w);
+  }
 #endif
   double p = fma(r, 0.5, -2.0 / 3.0);
   p = fma(r, p, 1.0);
   p = fma(r, p, -2.0);
-  return fma(dk, -1.386294361119890572454e+00, l2c + r * p);      // -2 ln 2
+  return fma(r, p, fma((double)lz, POCS_2LN2, l2c));
 }
 
-// sin / cos of a small angle |d| <= pi/256 (Taylor to d^5 / d^6: truncation < 1e-17)
+// sin / cos of a small angle |d| <= pi/256 in radians (the heading's remainder): sine to d^5 (truncation < 1e-17),
+// cosine to d^4 with the fitted coefficient above (error <= 5.0e-16)
 POCS_HD void pocs_sincos_small(double d, double* sd, double* cd, const pocs_vconst* V = nullptr) {
   const double z = d * d;
   const double ps = fma(z, 1.0 / 120.0, V ? V->sin_c3 : -1.0 / 6.0);
   *sd = fma(d * z, ps, d);
-  double pc = fma(z, -1.0 / 720.0, V ? V->cos_c4 : 1.0 / 24.0);
-  pc = fma(z, pc, -0.5);
+  const double pc = fma(z, POCS_COS_C4, -0.5);
   *cd = fma(z, pc, 1.0);
 }
 
-// sin and cos of the Box-Muller angle of a 32-bit word: sector = top 8 bits, d = the low 24 bits as an offset in
-// [-pi/256, pi/256) from that sector's table entry, i.e. the angle 2 pi (w - 2^23) 2^-32 -- uniform on the
-// circle with 2^32 levels like 2 pi w 2^-32 itself.
+// sin and cos of the Box-Muller angle of a 32-bit word: sector s = top 8 bits, k = the low 24 bits READ AS A SIGNED
+// NUMBER in [-2^23, 2^23) (one v_bfe_i32; v8 masked and subtracted 2^23), an offset from that sector's table entry:
+// the angle 2 pi (2^24 s + k) 2^-32.  Words <-> the 2^32 equally spaced angles is one to one (words with bit 23 set
+// land in the half sector BELOW their boundary, the others above), so the angle is uniform on those levels like
+// 2 pi w 2^-32 itself.  The polynomials run in k (above): k and k^2 are exact.
 POCS_HD void pocs_sincos_2pi_u32_tab(uint32_t w, const pocs_tables* T, double* sn, double* cs, const pocs_vconst* V = nullptr) {
   const int s = (int)(w >> 24);
-  const int f = (int)(w & 0x00ffffffu) - (1 << 23);                       // [-2^23, 2^23)
-  const double d = (double)f * (0x1p-24 * 2.45436926061702587187e-02);    // 2 pi / 256 per sector
-  double sd, cd;
-  pocs_sincos_small(d, &sd, &cd, V);
+  const double k = (double)((int32_t)(w << 8) >> 8);                      // sign-extended low 24 bits: [-2^23, 2^23)
+  const double z = k * k;
+  double ps = fma(z, POCS_BM_S5, V ? V->bm_s3 : POCS_BM_S3);
+  ps = fma(z, ps, POCS_BM_S1);
+  const double sd = k * ps;
+  const double pc = fma(z, POCS_BM_C4, V ? V->bm_c2 : POCS_BM_C2);
+  const double cd = fma(z, pc, 1.0);
   const double C = T->sc[s][0], S = T->sc[s][1];
   *sn = fma(S, cd, C * sd);
   *cs = fma(C, cd, -(S * sd));
 }
 
-// sin and cos of an arbitrary angle |x| < 2^18 by the same sectors: n = rint(x * 256/(2 pi)), d = x - n (2 pi / 256)
-// in two Cody-Waite steps -- pi/128 = P1 + P2, P1 its first 34 bits (n P1 is exact), P2 the rest rounded to double
-// (what is left of pi/128 after P2, 5.5e-29, times n < 2^24 is far below an ulp of d) -- so |d| <= pi/256 from
-// the table entry of sector n mod 256.  (v7: floor, three steps and half a sector's shift.)
+// sin and cos of an arbitrary angle by the same sectors: n = rint(x * 256/(2 pi)), d = x - n P in ONE fma with
+// P = pi/128 rounded to double (v8: two Cody-Waite steps): d carries n (P - pi/128), at most |x| * 4e-17 -- a
+// heading of a few turns is off by a few 1e-16 rad, what its own last bit is worth --, so |d| <= pi/256 (1 + 1e-15)
+// from the table entry of sector n mod 256.  Arguments: |x| < 2^20 (n must fit an int with room to spare).
 POCS_HD void pocs_sincos_tab(double x, const pocs_tables* T, double* sn, double* cs, const pocs_vconst* V = nullptr) {
   const double fn = rint(x * 4.07436654315252084757e+01);
   const int n = (int)fn;
-  double d = fma(-fn, 2.45436926052207127213e-02, x);    // P1
-  d = fma(-fn, 9.495469541415925389561e-13, d);          // P2
+  const double d = fma(-fn, 2.45436926061702587187e-02, x);
   double sd, cd;
   pocs_sincos_small(d, &sd, &cd, V);
   const int s = n & 255;
@@ -367,11 +399,10 @@ POCS_HD double pocs_div_by(double a, double b, double seed) {      // a / b; see
 POCS_HD double pocs_div(double a, double b) { return pocs_div_by(a, b, pocs_recip_seed(b)); }
 
 // Box-Muller pair of the mixture sampler, through the tables: one word for the radius,
-// u = (wr + 1) 2^-32 in (0,1], radius = sqrt(-2 log u) <= sqrt(64 ln 2) < 6.661 (the bound the
-// obstacle culling of k_gmm_step relies on), one word for the angle 2 pi wa 2^-32.
+// u = wr 2^-32, radius = sqrt(-2 log u) <= sqrt(64 ln 2) < 6.661 (the bound the obstacle culling of
+// k_gmm_step relies on; the level u = 0: pocs_radius2_unit32), one word for the angle.
 POCS_HD void pocs_normal_pair_w2(uint32_t wr, uint32_t wa, const pocs_tables* T, double* n0, double* n1, const pocs_vconst* V = nullptr) {
-  // |.|: at u = 1 (wr = 2^32 - 1) the table form lands a rounding error (~1e-16) on EITHER side of
-  // zero; the radius is then ~1e-8 instead of 0, never the square root of a negative number
+  // (|.|: free on the device, and the root's argument is then non-negative by construction, not by an error bound)
   const double rad = pocs_sqrt_normal(fabs(pocs_radius2_unit32(wr, T)));
   double sn, cs;
   pocs_sincos_2pi_u32_tab(wa, T, &sn, &cs, V);

@@ -32,7 +32,7 @@ def test_default_line_has_every_field():
     t = d["timing"]
     assert t["repeats"] >= 10 and t["ms_per_step_min"] <= t["ms_per_step_median"] <= t["ms_per_step_max"]
     assert d["ms_per_step"] == t["ms_per_step_median"] and t["timed_region_s"] > 0
-    assert d["numerics"].startswith("v8") and "numerics v8" in d["numerics"] and "Philox4x32-7" in d["config"]["random_stream"]
+    assert d["numerics"].startswith("v9") and "numerics v9" in d["numerics"] and "Philox4x32-7" in d["config"]["random_stream"]
     r = d["roofline"]
     # the limiter names the bound; the fraction is still the north star's: algorithmic bytes against the HBM peak
     assert r["bound"] == "fp64-issue+power" and r["reported_against"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
@@ -57,7 +57,7 @@ def test_full_size_line_carries_the_counter_records():
     """At the workload's own size the line carries the committed PMC figures: HBM bytes per launch (close to the
     algorithmic 26 B/eval) and the vector instructions per evaluation with the issue fraction they imply."""
     recs = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-    if not any(v.get("numerics") == "v8" and v.get("evals_per_launch") == 20_000_000 for v in recs.values()):
+    if not any(v.get("numerics") == "v9" and v.get("evals_per_launch") == 20_000_000 for v in recs.values()):
         pytest.skip("no counter record of the current numerics at this launch size yet")
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
                          capture_output=True, text=True, check=True, cwd=str(ROOT))

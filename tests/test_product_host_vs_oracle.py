@@ -45,7 +45,7 @@ def test_normal3_bitwise(hh, orc):
 
 
 def test_table_functions_bitwise_and_accurate(hh, orc):
-    """The table-driven radius / sincos of the hot path (numerics v8): product == oracle bit for bit, and both
+    """The table-driven radius / sincos of the hot path (numerics v9): product == oracle bit for bit, and both
     accurate to a few 1e-16 ABSOLUTE against libm -- six orders below the 4.7e-10 between two neighbouring levels
     of the 32-bit word the squared radius is a function of."""
     hh.hh_radius2_unit32.restype = C.c_double
@@ -57,33 +57,36 @@ def test_table_functions_bitwise_and_accurate(hh, orc):
     for w in ws:
         got = hh.hh_radius2_unit32(w)
         assert got == orc.radius2_unit32(w)
-        want = -2.0 * math.log1p(-(2 ** 32 - 1 - w) * 2.0 ** -32)      # u = 1 - (2^32 - 1 - w) 2^-32, exact; log1p keeps u near 1 accurate
+        if w == 0:
+            continue                                                  # the level u = 0: below
+        want = -2.0 * math.log1p(-(2 ** 32 - w) * 2.0 ** -32)          # u = w 2^-32 = 1 - (2^32 - w) 2^-32, exact; log1p keeps u near 1 accurate
         worst_abs = max(worst_abs, abs(got - want))
         worst_rel = max(worst_rel, abs(got - want) / max(abs(want), 1.0))
-    assert worst_rel < 6e-16 and worst_abs < 8e-15, (worst_rel, worst_abs)      # (v7: 3e-16 on the logarithm = 6e-16 here; 8e-15: an ulp of the largest value, 44.4)
-    assert 0.0 < abs(hh.hh_radius2_unit32(2 ** 32 - 1)) < 1e-15   # u = 1: radius ~0, but never exactly 0 (the device
-    assert all(hh.hh_radius2_unit32(2 ** 32 - 1 - j) > 4e-10 for j in range(1, 1000))    # sqrt sequence divides by it)
-    assert math.sqrt(hh.hh_radius2_unit32(0)) < 6.661             # the bound the obstacle culling uses
+    assert worst_rel < 6e-16 and worst_abs < 8e-15, (worst_rel, worst_abs)      # (8e-15: an ulp of the largest value, 44.4)
+    assert all(hh.hh_radius2_unit32(2 ** 32 - 1 - j) > 4e-10 for j in range(0, 1000))    # never 0: the device's sqrt sequence divides by it
+    assert math.sqrt(hh.hh_radius2_unit32(1)) < 6.661             # the bound the obstacle culling uses: the level 2^-32 ...
+    assert 2.04 < math.sqrt(hh.hh_radius2_unit32(0)) < 2.041       # ... the level 0 gets cell 0 with r = -1 and -1 leading zeros
     s, c = C.c_double(), C.c_double()
     for x in np.concatenate([rng.uniform(-20, 20, 8000), rng.uniform(-1e4, 1e4, 1000), [0.0, -0.0, 6.283185307179586, 1.5707963267948966],
                              (np.arange(-300, 300) + 0.5) * (math.pi / 128)]):       # (sector edges: rint's ties)
         hh.hh_sincos_tab(C.c_double(x), C.byref(s), C.byref(c))
         assert (s.value, c.value) == orc.sincos_tab(float(x))
-        assert abs(s.value - math.sin(x)) < 4e-16 * max(1.0, abs(x) / 10) and abs(c.value - math.cos(x)) < 4e-16 * max(1.0, abs(x) / 10)
+        # v9: the cosine's remainder polynomial stops at d^4 with a fitted coefficient (5.0e-16), the reduction is one fma
+        assert abs(s.value - math.sin(x)) < 9e-16 * max(1.0, abs(x) / 10) and abs(c.value - math.cos(x)) < 9e-16 * max(1.0, abs(x) / 10)
     for w in np.concatenate([rng.integers(0, 2 ** 32, 8000), [0, 2 ** 26 - 1, 2 ** 26, 2 ** 25, 2 ** 32 - 1, 2 ** 31, 2 ** 23, 2 ** 23 - 1]]):
         hh.hh_sincos_2pi_u32_tab(C.c_uint32(int(w)), C.byref(s), C.byref(c))
         assert (s.value, c.value) == orc.sincos_2pi_u32_tab(int(w))
-        # v8: the word's angle turned back by half a sector, i.e. the angle of the word w - 2^23 (mod 2^32), whose
-        # polynomial version is itself within 2.3e-16 of libm and has no range reduction to round
-        ws, wc = orc.sincos_2pi_u32((int(w) - 2 ** 23) & 0xFFFFFFFF)
-        assert abs(s.value - ws) < 4e-16 and abs(c.value - wc) < 4e-16
-        assert abs(s.value ** 2 + c.value ** 2 - 1.0) < 6e-16
+        # v9: the low 24 bits are a SIGNED offset from the sector's boundary: the angle of the word w itself where bit
+        # 23 is clear, of w - 2^24 where it is set; its polynomial version is within 2.3e-16 of libm, no reduction
+        ws, wc = orc.sincos_2pi_u32((int(w) - ((int(w) & 0x800000) << 1)) & 0xFFFFFFFF)
+        assert abs(s.value - ws) < 9e-16 and abs(c.value - wc) < 9e-16
+        assert abs(s.value ** 2 + c.value ** 2 - 1.0) < 1.5e-15
 
 
 def test_box_muller_radius_edge_words(hh, orc):
-    """Every radius word gives finite normals, bit-identical on both sides -- in particular
-    w = 2^32 - 1 (u = 1), where the table form of log may round to a value above zero, and the
-    words whose mantissa sits on a table-interval boundary."""
+    """Every radius word gives finite normals, bit-identical on both sides -- in particular w = 0 (the level
+    u = 0, which the build spec gives a radius of its own), w = 2^32 - 1 (the smallest), and the words whose
+    mantissa sits on a table-interval boundary."""
     a, b = C.c_double(), C.c_double()
     rng = np.random.default_rng(5)
     words = [2 ** 32 - 1 - j for j in range(64)] + list(range(64))
@@ -97,7 +100,7 @@ def test_box_muller_radius_edge_words(hh, orc):
             assert (a.value, b.value) == orc.normal_pair_w2(wr, wa), (wr, wa)
             assert a.value ** 2 + b.value ** 2 < 6.661 ** 2
     hh.hh_normal_pair_w2(C.c_uint32(2 ** 32 - 1), C.c_uint32(123), C.byref(a), C.byref(b))
-    assert abs(a.value) < 4e-8 and abs(b.value) < 4e-8           # u = 1: radius 0 up to the table form's rounding
+    assert 2.1e-5 < math.hypot(a.value, b.value) < 2.2e-5        # u = 1 - 2^-32: sqrt(2^-31)
 
 
 def test_sample_pairs_bitwise(hh, orc):

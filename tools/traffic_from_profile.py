@@ -11,7 +11,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 tag, key, name, path, evals, what = sys.argv[1:7]
-numerics = sys.argv[7] if len(sys.argv) > 7 else "v8"
+numerics = sys.argv[7] if len(sys.argv) > 7 else "v9"
 
 
 def mean_of(d, counter):
