@@ -93,8 +93,9 @@ POCS_HD bool pocs_pose_collides(double x, double y, double th, const pocs_footpr
     px = x + fma(cs, fp->dx, -(sn * fp->dy));
     py = y + fma(sn, fp->dx, cs * fp->dy);
   }
-  bool hit = false;
-  for (int m = 0; m < M; ++m) hit = hit | pocs_box_hit(px, py, sn, cs, fp->hx, fp->hy, obs + m * POCS_OBS_STRIDE);
+  bool hit = false;                             // (set under a condition, not or-ed in: see pocs_pair_collides)
+  for (int m = 0; m < M; ++m)
+    if (pocs_box_hit(px, py, sn, cs, fp->hx, fp->hy, obs + m * POCS_OBS_STRIDE)) hit = true;
   return hit;
 }
 
@@ -127,7 +128,10 @@ POCS_HD void pocs_pair_collides(const double x[2], const double y[2], const doub
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int h = 0; h < 2; ++h) hit[h] = hit[h] | pocs_box_hit(px[h], py[h], sn[h], cs[h], fp->hx, fp->hy, o);
+    // `if (...) hit = true`, not `hit |= ...`: the flag then stays a lane mask in scalar registers across the
+    // loop, merged by scalar instructions; or-ed in as an integer it cost a v_cndmask and a v_or per record and pose
+    for (int h = 0; h < 2; ++h)
+      if (pocs_box_hit(px[h], py[h], sn[h], cs[h], fp->hx, fp->hy, o)) hit[h] = true;
   }
 }
 

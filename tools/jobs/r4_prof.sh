@@ -23,7 +23,7 @@ one() {   # TAG NAME KERNEL_KEY TRAFFIC_KEY PATH EVALS "description" bench args.
   rm -rf $O/prof_$TAG $O/pmc_${TAG}_write $O/pmc_${TAG}_fetch $O/pmc_${TAG}_sq $O/pmc_${TAG}_sq2
   head -3 $O/${NAME}_kernel_stats.csv | cut -c1-150
 }
-one r4c_d20 r04_c_driver20 k_gmm_step "k_gmm_step<3, true" gmm 10000000 "python3 bench.py --steps 20 --warmup 5 (the driver's invocation: 20 runs x 10^6 samples per waypoint, K=3, issued as TWO launches of 10 runs side by side; numerics v8, end of round 4)" --steps 20 --warmup 5
-one r4c_b64 r04_c_batch64 k_gmm_step "k_gmm_step<3, true" gmm 32000000 "python3 bench.py --steps 256 --warmup 64 (the default: 64 runs x 10^6 samples per waypoint, K=3, TWO launches of 32 runs side by side; numerics v8)" --steps 256 --warmup 64
-one r4c_cfg3 r04_c_cfg3 k_gmm_step "k_gmm_step<8, true" gmm 80000000 "python3 bench.py --workload cfg3 --steps 16 --warmup 16 (16 runs x 10^7 samples per waypoint, K=8, 500 waypoints, TWO launches of 8 runs side by side; numerics v8)" --workload cfg3 --steps 16 --warmup 16
+one r4d_d20 r04_d_driver20 k_gmm_step "k_gmm_step<3, true" gmm 10000000 "python3 bench.py --steps 20 --warmup 5 (the driver's invocation: 20 runs x 10^6 samples per waypoint, K=3, issued as TWO launches of 10 runs side by side; numerics v9, end of round 4)" --steps 20 --warmup 5
+one r4d_b64 r04_d_batch64 k_gmm_step "k_gmm_step<3, true" gmm 32000000 "python3 bench.py --steps 256 --warmup 64 (the default: 64 runs x 10^6 samples per waypoint, K=3, TWO launches of 32 runs side by side; numerics v9)" --steps 256 --warmup 64
+one r4d_cfg3 r04_d_cfg3 k_gmm_step "k_gmm_step<8, true" gmm 80000000 "python3 bench.py --workload cfg3 --steps 16 --warmup 16 (16 runs x 10^7 samples per waypoint, K=8, 500 waypoints, TWO launches of 8 runs side by side; numerics v9)" --workload cfg3 --steps 16 --warmup 16
 cp profiles/traffic.json gpurun_out/traffic_r04.json
