@@ -57,7 +57,7 @@ def test_full_size_line_carries_the_counter_records():
     """At the workload's own size the line carries the committed PMC figures: HBM bytes per launch (close to the
     algorithmic 26 B/eval) and the vector instructions per evaluation with the issue fraction they imply."""
     recs = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-    if not any(v.get("numerics") == "v9" and v.get("evals_per_launch") == 20_000_000 for v in recs.values()):
+    if not any(v.get("numerics") == "v9" and v.get("evals_per_launch") in (10_000_000, 20_000_000) for v in recs.values()):
         pytest.skip("no counter record of the current numerics at this launch size yet")
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
                          capture_output=True, text=True, check=True, cwd=str(ROOT))
