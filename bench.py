@@ -784,7 +784,8 @@ def main():
     if tj.exists():
         recs = [(k, v) for k, v in json.loads(tj.read_text()).items()
                 if v.get("path", "gmm" if k.startswith("cfg") and not k.startswith("cfg5") else "mc") == path and v.get("evals_per_launch")
-                and v.get("numerics", "v6") == NUMERICS]
+                and v.get("numerics", "v6") == NUMERICS
+                and (path != "gmm" or (v.get("components") or (8 if "cfg3" in k else 3)) == K)]     # another K is another kernel
         if recs:
             k, rec = min(recs, key=lambda kv: abs(kv[1]["evals_per_launch"] - units))
             if 0.5 <= rec["evals_per_launch"] / units <= 2.0:

@@ -157,6 +157,7 @@ __device__ __forceinline__ void acquire_agent() {
 #define POCS_ADV_STAMP(i) do { } while (0)
 #define POCS_TUNE_NORMALS(...) __VA_ARGS__
 #define POCS_TUNE_COLLIDE(...) __VA_ARGS__
+#define POCS_TUNE_COLLIDE_STATS() do { } while (0)
 #define POCS_TUNE_SKIP_MOMENTS false
 #define POCS_TUNE_MOMENTS_ALT() do { } while (0)
 #endif
@@ -659,6 +660,7 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
       ts[h] = fma(p[8], zz[h][2], fma(p[7], zz[h][1], fma(p[6], zz[h][0], p[2])));
       ks[h] = k;
     }
+    POCS_TUNE_COLLIDE_STATS();
     POCS_TUNE_COLLIDE(pocs_pair_collides(xs, ys, ts, &fp, s_keep, nkeep, s_tab, vc, hits));
     if constexpr (POCS_TUNE_SKIP_MOMENTS) { POCS_TUNE_MOMENTS_ALT(); } else {
     // T1 sums over the collision-free samples of the component being accumulated:

@@ -23,7 +23,16 @@ __device__ unsigned long long g_stamps[24 * 256];            // a set per block 
 #define POCS_STAMP_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(POCS_STAMP_AT(i), 1ull); } while (0)
 #define POCS_ADV_STAMP_BEGIN() unsigned long long t_ = wall_clock64()
 #define POCS_ADV_STAMP(i) do { if (tid == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(POCS_STAMP_AT(i), n_ - t_); t_ = n_; } } while (0)
+// how often the footprint test has anything to do: iterations (a wave's 128 samples), those of runs that kept any obstacle
+// record, those with ANY lane inside any kept record's broad-phase box; kept records and such lanes per iteration
+#define POCS_TUNE_COLLIDE_STATS() do { bool pass_ = false; \
+    for (int m_ = 0; m_ < nkeep; ++m_) { const double* o_ = s_keep + m_ * POCS_OBS_STRIDE; \
+      for (int h_ = 0; h_ < 2; ++h_) pass_ = pass_ || (fabs(o_[0] - xs[h_]) <= o_[6] && fabs(o_[1] - ys[h_]) <= o_[7]); } \
+    const unsigned long long b_ = __ballot(pass_); \
+    if ((threadIdx.x & 63) == 0) { atomicAdd(POCS_STAMP_AT(16), 1ull); if (nkeep > 0) atomicAdd(POCS_STAMP_AT(17), 1ull); if (b_) atomicAdd(POCS_STAMP_AT(18), 1ull); \
+      atomicAdd(POCS_STAMP_AT(19), (unsigned long long)nkeep); atomicAdd(POCS_STAMP_AT(20), (unsigned long long)__popcll(b_)); } } while (0)
 #else
+#define POCS_TUNE_COLLIDE_STATS() do { } while (0)
 #define POCS_STAMP_BEGIN() do { } while (0)
 #define POCS_STAMP(i) do { } while (0)
 #define POCS_STAMP_COUNT(i) do { } while (0)
@@ -76,6 +85,8 @@ extern "C" void pocs_stamps_report() {
           "ticket + barrier %.2f ; per closer: close_sums %.2f | advance %.2f (staging %.2f, components (wave 0) %.2f, -> the counts lane %.2f, normalise + publish + drain %.2f)\n",
           nb, nc, 0.01 * h[0] / nb, 0.01 * h[1] / nb, 0.01 * h[2] / nb, 0.01 * h[3] / nb, 0.01 * h[4] / nb, 0.01 * h[5] / nc, 0.01 * h[6] / nc,
           0.01 * h[8] / nc, 0.01 * h[9] / nc, 0.01 * h[10] / nc, 0.01 * h[11] / nc);
+  if (h[16]) fprintf(stderr, "[stamps] footprint test: %llu wave iterations, %.1f %% in runs with kept records (%.2f records per iteration), %.1f %% with a lane inside a record's broad-phase box (%.2f lanes per iteration)\n",
+                     h[16], 100.0 * h[17] / h[16], (double)h[19] / h[16], 100.0 * h[18] / h[16], (double)h[20] / h[16]);
   for (auto& v : all) v = 0;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), all, sizeof all);
 }

@@ -6,6 +6,7 @@ usage: traffic_from_profile.py TAG KEY NAME PATH EVALS_PER_LAUNCH "what"     (KE
 import collections
 import csv
 import json
+import re
 import sys
 from pathlib import Path
 
@@ -30,7 +31,9 @@ def mean_of(d, counter):
 w, nw, g = mean_of("pmc_%s_write" % tag, "WRITE_SIZE")
 f, nf, _ = mean_of("pmc_%s_fetch" % tag, "FETCH_SIZE")
 v, nv, _ = mean_of("pmc_%s_sq" % tag, "SQ_INSTS_VALU")
+mk = re.search(r"k_gmm_step<(\d+)", key)
 rec = {"bytes_per_launch": int(round((2 * f + w) * 1024)), "evals_per_launch": int(evals), "path": path, "numerics": numerics,
+       "components": int(mk.group(1)) if mk else None,
        "valu_insts_per_launch": v,
        "source": "profiles/%s_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE)*1024 B and SQ_INSTS_VALU per launch (%s; grid %d threads, %d / %d / %d dispatches)"
                  % (name, what, g, nw, nf, nv)}
