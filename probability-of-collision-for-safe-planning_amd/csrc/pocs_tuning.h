@@ -29,8 +29,12 @@ __device__ unsigned long long g_stamps[24 * 256];            // a set per block 
     for (int m_ = 0; m_ < nkeep; ++m_) { const double* o_ = s_keep + m_ * POCS_OBS_STRIDE; \
       for (int h_ = 0; h_ < 2; ++h_) pass_ = pass_ || (fabs(o_[0] - xs[h_]) <= o_[6] && fabs(o_[1] - ys[h_]) <= o_[7]); } \
     const unsigned long long b_ = __ballot(pass_); \
+    bool own_ = false; { const double* p_ = &s_par[ks[0] * POCS_PARAM_STRIDE]; const double ex_ = 6.67 * fabs(p_[3]), ey_ = 6.67 * (fabs(p_[4]) + fabs(p_[5])); \
+      for (int m_ = 0; m_ < nkeep; ++m_) { const double* o_ = s_keep + m_ * POCS_OBS_STRIDE; \
+        own_ = own_ || (fabs(o_[0] - p_[0]) <= o_[6] + ex_ && fabs(o_[1] - p_[1]) <= o_[7] + ey_); } } \
+    const unsigned long long c_ = __ballot(own_); \
     if ((threadIdx.x & 63) == 0) { atomicAdd(POCS_STAMP_AT(16), 1ull); if (nkeep > 0) atomicAdd(POCS_STAMP_AT(17), 1ull); if (b_) atomicAdd(POCS_STAMP_AT(18), 1ull); \
-      atomicAdd(POCS_STAMP_AT(19), (unsigned long long)nkeep); atomicAdd(POCS_STAMP_AT(20), (unsigned long long)__popcll(b_)); } } while (0)
+      atomicAdd(POCS_STAMP_AT(19), (unsigned long long)nkeep); atomicAdd(POCS_STAMP_AT(20), (unsigned long long)__popcll(b_)); if (c_ & 1ull) atomicAdd(POCS_STAMP_AT(21), 1ull); } } while (0)
 #else
 #define POCS_TUNE_COLLIDE_STATS() do { } while (0)
 #define POCS_STAMP_BEGIN() do { } while (0)
@@ -85,8 +89,8 @@ extern "C" void pocs_stamps_report() {
           "ticket + barrier %.2f ; per closer: close_sums %.2f | advance %.2f (staging %.2f, components (wave 0) %.2f, -> the counts lane %.2f, normalise + publish + drain %.2f)\n",
           nb, nc, 0.01 * h[0] / nb, 0.01 * h[1] / nb, 0.01 * h[2] / nb, 0.01 * h[3] / nb, 0.01 * h[4] / nb, 0.01 * h[5] / nc, 0.01 * h[6] / nc,
           0.01 * h[8] / nc, 0.01 * h[9] / nc, 0.01 * h[10] / nc, 0.01 * h[11] / nc);
-  if (h[16]) fprintf(stderr, "[stamps] footprint test: %llu wave iterations, %.1f %% in runs with kept records (%.2f records per iteration), %.1f %% with a lane inside a record's broad-phase box (%.2f lanes per iteration)\n",
-                     h[16], 100.0 * h[17] / h[16], (double)h[19] / h[16], 100.0 * h[18] / h[16], (double)h[20] / h[16]);
+  if (h[16]) fprintf(stderr, "[stamps] footprint test: %llu wave iterations, %.1f %% in runs with kept records (%.2f records per iteration), %.1f %% with a lane inside a record's broad-phase box (%.2f lanes per iteration); %.1f %% where the box of the wave's OWN component (first lane's) reaches a kept record\n",
+                     h[16], 100.0 * h[17] / h[16], (double)h[19] / h[16], 100.0 * h[18] / h[16], (double)h[20] / h[16], 100.0 * h[21] / h[16]);
   for (auto& v : all) v = 0;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), all, sizeof all);
 }
