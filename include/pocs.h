@@ -202,6 +202,13 @@ int pocs_get_exchange_wait(pocs_ctx* ctx, double* min_median_max_us);  /* sharde
                                                                           pocs_gmm_sample_exchange_local): how long the closers of the last begin..end sequence
                                                                           waited for the other ranks' moments, over its (run, waypoint) pairs -- the first thing
                                                                           to read when a multi-GPU run scales badly (ranks that drift apart show here) */
+int pocs_probe_device_math(pocs_ctx* ctx, int n, const uint32_t* radius_words, const uint32_t* angle_words, const double* headings,
+                           double* z0, double* z1, double* sn, double* cs, double* radius2);
+/* TEST HOOK, no counterpart in the reference: the DEVICE's table-driven sampler functions on inputs the
+   caller picks -- per i < n the Box-Muller pair (z0, z1) of the words (radius_words[i], angle_words[i]) with its squared radius,
+   and sin / cos of headings[i] as the footprint test evaluates them -- through the same inline functions, tables and pinned
+   constants as k_gmm_step.  A free-running launch meets a given word once in 2^32 draws; this puts the edge words (0, the
+   cells' boundaries, 2^32 - 1, a heading on a sector's tie) in front of the oracle directly (tests/test_gpu_parity.py). */
 int pocs_get_sequence_time(pocs_ctx* ctx, double* ms, int* concurrent);  /* POCS_OPT_PROFILE=1, whole-run GMM calls: first sampling launch -> end of the last one, and how many
                                                                             sub-batches of the call were in flight side by side (their launches overlap: DESIGN.md section 5) */
 

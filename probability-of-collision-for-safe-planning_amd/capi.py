@@ -75,6 +75,7 @@ SIGNATURES = {
     "pocs_get_kernel_time": (C.c_int, [_vp, _dp, C.POINTER(C.c_longlong)]),
     "pocs_get_sequence_time": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "pocs_get_exchange_wait": (C.c_int, [_vp, _dp]),
+    "pocs_probe_device_math": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _dp, _dp, _dp, _dp, _dp, _dp]),
 }
 
 _lib = None
@@ -414,6 +415,19 @@ class Context:
         v = (C.c_double * 3)()
         self._chk(self.lib.pocs_get_exchange_wait(self.h, v))
         return v[0], v[1], v[2]
+
+    def probe_device_math(self, radius_words, angle_words, headings):
+        """Test hook: the device's table-driven sampler functions on chosen inputs -> (z0, z1, sin, cos, radius^2) arrays."""
+        wr = np.ascontiguousarray(radius_words, dtype=np.uint32)
+        wa = np.ascontiguousarray(angle_words, dtype=np.uint32)
+        x = np.ascontiguousarray(headings, dtype=np.float64)
+        n = len(wr)
+        assert len(wa) == n and len(x) == n
+        out = [np.empty(n) for _ in range(5)]
+        u32 = C.POINTER(C.c_uint32)
+        self._chk(self.lib.pocs_probe_device_math(self.h, n, wr.ctypes.data_as(u32), wa.ctypes.data_as(u32), x.ctypes.data_as(_dp),
+                                                  *[o.ctypes.data_as(_dp) for o in out]))
+        return tuple(out)
 
     def kernel_time(self):
         ms, n = C.c_double(), C.c_longlong()

@@ -316,13 +316,16 @@ int check_common(pocs_ctx* c) {
   return POCS_OK;
 }
 
+int upload_tables(pocs_ctx* c) {               // log / sector tables of the numerics spec, once
+  if (c->d_tables.p) return POCS_OK;
+  pocs_tables T;
+  pocs_tables_init(&T);
+  if (int r = ensure(c, c->d_tables, sizeof T)) return r;
+  HIPCHK(c, hipMemcpy(c->d_tables.p, &T, sizeof T, hipMemcpyHostToDevice));
+  return POCS_OK;
+}
 int upload_static(pocs_ctx* c) {
-  if (!c->d_tables.p) {                       // log / sector tables of the numerics spec, once
-    pocs_tables T;
-    pocs_tables_init(&T);
-    if (int r = ensure(c, c->d_tables, sizeof T)) return r;
-    HIPCHK(c, hipMemcpy(c->d_tables.p, &T, sizeof T, hipMemcpyHostToDevice));
-  }
+  if (int r = upload_tables(c)) return r;
   if (c->env_dirty) {
     pocs_env_dev env;
     memset(&env, 0, sizeof env);
@@ -1662,6 +1665,33 @@ int pocs_measure_fill_bandwidth(pocs_ctx* c, long long bytes, double* gbps) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(a);
   *gbps = best;
+  return rc;
+}
+
+// Test hook: the device's table-driven sampler functions on chosen inputs (include/pocs.h).
+int pocs_probe_device_math(pocs_ctx* c, int n, const uint32_t* radius_words, const uint32_t* angle_words, const double* headings,
+                           double* z0, double* z1, double* sn, double* cs, double* radius2) {
+  if (!c || n < 1 || n > (1 << 20) || !radius_words || !angle_words || !headings || !z0 || !z1 || !sn || !cs || !radius2) return c ? fail(c, POCS_E_ARG, "pocs_probe_device_math: 1 <= n <= 2^20, no null pointers") : POCS_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int r = upload_tables(c)) return r;
+  const size_t nw = (size_t)n * sizeof(uint32_t), nd = (size_t)n * sizeof(double);
+  char* buf = nullptr;                         // [wr | wa | x | out 5 n]
+  HIPCHK(c, hipMalloc((void**)&buf, 2 * nw + 6 * nd + 64));
+  uint32_t* d_wr = (uint32_t*)buf;
+  uint32_t* d_wa = d_wr + n;
+  double* d_x = (double*)(buf + ((2 * nw + 15) & ~(size_t)15));
+  double* d_out = d_x + n;
+  int rc = POCS_OK;
+  if (hipMemcpy(d_wr, radius_words, nw, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_wa, angle_words, nw, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_x, headings, nd, hipMemcpyHostToDevice) != hipSuccess)
+    rc = fail(c, POCS_E_DEVICE, "probe upload failed");
+  if (rc == POCS_OK && pocs_launch_probe_math((const pocs_tables*)c->d_tables.p, n, d_wr, d_wa, d_x, d_out, c->stream) != hipSuccess)
+    rc = fail(c, POCS_E_DEVICE, "probe launch failed");
+  if (rc == POCS_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, POCS_E_DEVICE, "probe kernel failed");
+  double* dst[5] = {z0, z1, sn, cs, radius2};
+  for (int j = 0; j < 5 && rc == POCS_OK; ++j)
+    if (hipMemcpy(dst[j], d_out + (size_t)j * n, nd, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(c, POCS_E_DEVICE, "probe download failed");
+  (void)hipFree(buf);
   return rc;
 }
 

@@ -140,6 +140,7 @@ hipError_t pocs_launch_gmm_close(int K, const pocs_gmm_launch& a, hipStream_t s)
 hipError_t pocs_launch_gmm_exchange(int K, const pocs_gmm_launch& a, const pocs_xchg_dev& x, hipStream_t s);   // grid = a.nruns
 hipError_t pocs_launch_copy(const void* src, void* dst, long long bytes, hipStream_t s);
 hipError_t pocs_launch_fill(void* dst, long long bytes, hipStream_t s);
+hipError_t pocs_launch_probe_math(const pocs_tables* tables, int n, const uint32_t* wr, const uint32_t* wa, const double* x, double* out, hipStream_t s);   // out: 5 x n
 hipError_t pocs_launch_mc_init(int nblk, const pocs_mc_launch& a, hipStream_t s);
 hipError_t pocs_launch_mc_step(int nblk, const pocs_mc_launch& a, hipStream_t s);
 hipError_t pocs_launch_mc_fused(int nblk, const pocs_mc_launch& a, hipStream_t s);

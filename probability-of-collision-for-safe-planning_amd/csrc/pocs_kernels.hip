@@ -1231,6 +1231,28 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_fill(double2* __restrict__ dst, 
     for (int u = 0; u < 4; ++u) if (i + u * POCS_BLOCK < n) __builtin_nontemporal_store(x, d + i + u * POCS_BLOCK);
   }
 }
+// The hot path's table-driven sampler functions on words / angles the caller picks (pocs_probe_device_math: a test
+// hook -- the words a free-running launch meets once in 2^32 draws, the cells' edges, a heading on a sector's tie):
+// the same inline functions, the tables staged in LDS as k_gmm_step stages them, the constants pinned as there.
+__global__ __launch_bounds__(POCS_BLOCK) void k_probe_math(const pocs_tables* __restrict__ tables, int n, const uint32_t* __restrict__ wr,
+                                                          const uint32_t* __restrict__ wa, const double* __restrict__ x,
+                                                          double* __restrict__ out) {
+  __shared__ pocs_tables s_tab;
+  stage_tables(tables, &s_tab);
+  __syncthreads();
+  POCS_VCONST(vc_);
+  for (int i = threadIdx.x; i < n; i += POCS_BLOCK) {
+    double z0, z1, sn, cs;
+    pocs_normal_pair_w2(wr[i], wa[i], &s_tab, &z0, &z1, &vc_);
+    pocs_sincos_tab(x[i], &s_tab, &sn, &cs, &vc_);
+    out[i] = z0; out[n + i] = z1; out[2 * n + i] = sn; out[3 * n + i] = cs;
+    out[4 * n + i] = pocs_radius2_unit32(wr[i], &s_tab);
+  }
+}
+hipError_t pocs_launch_probe_math(const pocs_tables* tables, int n, const uint32_t* wr, const uint32_t* wa, const double* x, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_probe_math, dim3(1), dim3(POCS_BLOCK), 0, s, tables, n, wr, wa, x, out);
+  return hipGetLastError();
+}
 hipError_t pocs_launch_fill(void* dst, long long bytes, hipStream_t s) {
   hipLaunchKernelGGL(k_fill, dim3(8192), dim3(POCS_BLOCK), 0, s, (double2*)dst, bytes / 16, 1.5);
   return hipGetLastError();

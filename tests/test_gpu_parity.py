@@ -892,3 +892,32 @@ def test_span_profile_times_the_replayed_graph(pocs, plan, env):
     assert p0 == p1 == p2
     assert n2 == n1 == 56 and 0.0 < ms2 < 1.25 * ms1
     assert nm == 55 and msm > 0.0
+
+
+def test_device_sampler_functions_on_edge_words(ctx, orc):
+    """The device's table-driven Box-Muller pair and heading sine / cosine on inputs a free-running launch meets
+    once in 2^32 draws, bit for bit against the oracle: the radius word 0 (the level u = 0: no logarithm; numerics v9
+    gives it what the hardware's frexp and v_ffbh_u32 return for a zero word, and the oracle writes that case out),
+    2^32 - 1, every power of two and its neighbours, the 512 cells' first and last words in several octaves; angle
+    words on both sides of bit 23 and on the sector boundaries; headings on the sectors' ties, at zero, far out."""
+    rng = np.random.default_rng(77)
+    wr = [0, 1, 2, 3, 2 ** 32 - 1, 2 ** 32 - 2, 2 ** 31, 2 ** 31 - 1, 2 ** 31 + 1]
+    wr += [(1 << e) + d for e in range(1, 32) for d in (-1, 0, 1)]
+    wr += [(1 << e) + (i << max(e - 9, 0)) - d for e in (9, 10, 17, 24, 31) for i in range(0, 512, 7) for d in (0, 1)]
+    wr += [int(v) for v in rng.integers(0, 2 ** 32, 4000)]
+    wr = np.array([w & 0xFFFFFFFF for w in wr], dtype=np.uint32)
+    n = len(wr)
+    wa_edge = [0, 1, 2 ** 23 - 1, 2 ** 23, 2 ** 23 + 1, 2 ** 24 - 1, 2 ** 24, 2 ** 24 + 2 ** 23, 2 ** 31, 2 ** 32 - 1, 0x7F800000, 0x7F7FFFFF]
+    wa = np.array((wa_edge * (n // len(wa_edge) + 1))[:n], dtype=np.uint64)
+    wa[len(wa_edge) * 20:] = rng.integers(0, 2 ** 32, n - len(wa_edge) * 20)
+    wa = wa.astype(np.uint32)
+    x = np.concatenate([[0.0, -0.0, math.pi, -math.pi, 2 * math.pi, 1e-300, 123456.789, -99999.5],
+                        (np.arange(-200, 200) + 0.5) * (math.pi / 128),                  # rint's ties
+                        rng.uniform(-30, 30, n)])[:n]
+    z0, z1, sn, cs, r2 = ctx.probe_device_math(wr, wa, x)
+    for i in range(n):
+        want = orc.normal_pair_w2(int(wr[i]), int(wa[i]))
+        assert (z0[i], z1[i]) == want, (i, int(wr[i]), int(wa[i]), (z0[i], z1[i]), want)
+        assert r2[i] == orc.radius2_unit32(int(wr[i])), (i, int(wr[i]))
+        assert (sn[i], cs[i]) == orc.sincos_tab(float(x[i])), (i, x[i])
+    assert 2.04 < math.sqrt(r2[0]) < 2.041 and np.all(np.isfinite(z0)) and np.all(np.isfinite(z1))
