@@ -26,4 +26,7 @@ one() {   # TAG NAME KERNEL_KEY TRAFFIC_KEY PATH EVALS "description" bench args.
 one r4d_d20 r04_d_driver20 k_gmm_step "k_gmm_step<3, true" gmm 10000000 "python3 bench.py --steps 20 --warmup 5 (the driver's invocation: 20 runs x 10^6 samples per waypoint, K=3, issued as TWO launches of 10 runs side by side; numerics v9, end of round 4)" --steps 20 --warmup 5
 one r4d_b64 r04_d_batch64 k_gmm_step "k_gmm_step<3, true" gmm 32000000 "python3 bench.py --steps 256 --warmup 64 (the default: 64 runs x 10^6 samples per waypoint, K=3, TWO launches of 32 runs side by side; numerics v9)" --steps 256 --warmup 64
 one r4d_cfg3 r04_d_cfg3 k_gmm_step "k_gmm_step<8, true" gmm 80000000 "python3 bench.py --workload cfg3 --steps 16 --warmup 16 (16 runs x 10^7 samples per waypoint, K=8, 500 waypoints, TWO launches of 8 runs side by side; numerics v9)" --workload cfg3 --steps 16 --warmup 16
+# the same kernel with ONE launch of 20 runs per waypoint (POCS_SUB_BATCHES=1): the form in which a kernel trace's duration and the bench line's
+# span-timed period are the same quantity (with two sub-batches side by side the profiler keeps the twins from overlapping as they do alone)
+POCS_SUB_BATCHES=1 one r4e_d20 r04_e_driver20_single k_gmm_step "k_gmm_step<3, true" gmm 20000000 "POCS_SUB_BATCHES=1 python3 bench.py --steps 20 --warmup 5 (20 runs x 10^6 samples per waypoint, K=3, ONE launch per waypoint; numerics v9, the round's final kernel)" --steps 20 --warmup 5
 cp profiles/traffic.json gpurun_out/traffic_r04.json
