@@ -27,7 +27,7 @@
 // Block size and slice count are part of the NUMERICS (the summation tree is defined on chunks of 512 pairs, 64-lane
 // waves and at most 256 virtual slices; oracle/pocs_oracle.c::tree_moments restates exactly these): a build with
 // other values would produce other last bits under the same version string.
-static_assert(POCS_GMM_BLOCK_OF(3) == 512 && POCS_GMM_MAX_VS == 256, "summation tree of numerics v8: 512-pair chunks, 256 virtual slices");
+static_assert(POCS_GMM_BLOCK_OF(3) == 512 && POCS_GMM_MAX_VS == 256, "summation tree (numerics v7 and later): 512-pair chunks, 256 virtual slices");
 #define POCS_GMM_SUB 32        // units whose wave sums a block holds in LDS at a time (64 runs x 256 slices / 512 blocks)
 #define POCS_UNIT_SUMS 10      // survivors + the nine sums
 #define POCS_FLUSH_ROWS 5      // flush_unit's transpose scratch per wave: 5 rows of 64 lane values,
