@@ -3,8 +3,10 @@ against the independent oracle restatement -- bit for bit where the numerics spe
 operation order (CPU only; the GPU versions of the same checks live in test_gpu_parity.py)."""
 import ctypes as C
 import math
+from pathlib import Path
 
 import numpy as np
+import pytest
 
 from conftest import dp
 
@@ -327,3 +329,38 @@ def test_footprint_extent_bounds_every_heading_of_the_range(hh):
         assert scan <= got <= rr * (1 + 1e-15), (rx, ry, lo, hi, got, scan)
         # tight: the scan's maximum, or the bounding radius where a peak of f lies inside the range
         assert got - scan < 1e-6 or (got == rr and rr - scan < 1e-6 + 1e-3 * width ** 2), (rx, ry, lo, hi, got, scan)
+
+
+def test_v9_constants_are_what_the_build_spec_says():
+    """The scaled Box-Muller coefficients and the cosine's fitted d^4 coefficient of numerics v9, as literals in
+    csrc/pocs_math.h and oracle/pocs_oracle.c, against their definitions evaluated with 60 digits (mpmath; the
+    script that printed them: tools/make_v9_constants.py): a = 2 pi 2^-32, S1 = a, S3 = -a^3/6, S5 = a^5/120,
+    C2 = -a^2/2, C4 = C4' a^4 with C4' the coefficient of least maximum error of 1 - z/2 + C4' z^2 against
+    cos(sqrt z) on [0, (pi/256)^2], and P = pi/128."""
+    mp = pytest.importorskip("mpmath")
+    import re
+    mp.mp.dps = 60
+    root = Path(__file__).resolve().parents[1]
+    hdr = (root / "probability-of-collision-for-safe-planning_amd" / "csrc" / "pocs_math.h").read_text()
+    orc_src = (root / "oracle" / "pocs_oracle.c").read_text()
+    lit = {m.group(1): float(m.group(2)) for m in re.finditer(r"#define (POCS_(?:BM_S1|BM_S3|BM_S5|BM_C2|BM_C4|COS_C4|2LN2)) (-?[0-9.]+e[-+][0-9]+)", hdr)}
+    assert set(lit) == {"POCS_BM_S1", "POCS_BM_S3", "POCS_BM_S5", "POCS_BM_C2", "POCS_BM_C4", "POCS_COS_C4", "POCS_2LN2"}
+    a = 2 * mp.pi / mp.mpf(2) ** 32
+    c4 = mp.mpf(lit["POCS_COS_C4"])
+    want = {"POCS_BM_S1": a, "POCS_BM_S3": -a ** 3 / 6, "POCS_BM_S5": a ** 5 / 120, "POCS_BM_C2": -a * a / 2, "POCS_BM_C4": c4 * a ** 4,
+            "POCS_2LN2": 2 * mp.log(2)}
+    for k, v in want.items():
+        assert lit[k] == float(v), (k, lit[k], float(v))                 # the nearest double of the definition
+    # the fitted coefficient: the largest error of the cosine's polynomial on the interval is the 5.0e-16 the spec states,
+    # and moving the coefficient by 1e-9 either way makes it larger (it IS the minimiser, to that resolution)
+    Z = (mp.pi / 256) ** 2
+    def worst(c):
+        return max(abs(mp.cos(mp.sqrt(Z * i / 400)) - (1 - Z * i / 800 + c * (Z * i / 400) ** 2)) for i in range(1, 401))
+    w0 = worst(c4)
+    assert mp.mpf("4.9e-16") < w0 < mp.mpf("5.1e-16")
+    assert worst(c4 + mp.mpf("1e-9")) > w0 and worst(c4 - mp.mpf("1e-9")) > w0
+    # both files carry the same literals (the oracle spells them without the macro names)
+    for k in ("POCS_BM_S1", "POCS_BM_S3", "POCS_BM_S5", "POCS_BM_C2", "POCS_BM_C4", "POCS_COS_C4", "POCS_2LN2"):
+        text = re.search(r"#define %s (\S+)" % k, hdr).group(1)
+        assert text in orc_src, (k, text)
+    assert float(mp.pi / 128) == 2.45436926061702587187e-02 and "2.45436926061702587187e-02" in hdr and "2.45436926061702587187e-02" in orc_src
