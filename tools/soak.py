@@ -14,6 +14,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(7)
 plan, env = pocs_amd.load_plan(), pocs_amd.load_env()
 t0, runs, bad = time.time(), 0, 0
+t_said = t0
 with pocs_amd.Context(0) as c:
     while time.time() - t0 < budget:
         K = int(rng.integers(1, 9))
@@ -39,6 +40,9 @@ with pocs_amd.Context(0) as c:
         c.set_batch(1)
         c.set_seed(seed)
         c.run_gmm_estimation()                      # run 0 on its own launch: the same bits as run 0 of the batch
+        if time.time() - t_said > 60:                # (a silent job is taken for a hung one)
+            t_said = time.time()
+            print("... %d runs, %.0f s, %d mismatches" % (runs, t_said - t0, bad), flush=True)
         if (c.batch_probabilities()[0],) != ref[0][:1]:
             bad += 1
             print("MISMATCH batch vs single K=%d N=%d R=%d seed=%d" % (K, N, R, seed))
