@@ -28,6 +28,7 @@
 // waves and at most 256 virtual slices; oracle/pocs_oracle.c::tree_moments restates exactly these): a build with
 // other values would produce other last bits under the same version string.
 static_assert(POCS_GMM_BLOCK_OF(3) == 512 && POCS_GMM_MAX_VS == 256, "summation tree (numerics v7 and later): 512-pair chunks, 256 virtual slices");
+#define POCS_LONE_PRE 3        // lone form: iterations of a unit whose normals the block's head draws ahead (72 KB of LDS at 512 threads)
 #define POCS_GMM_SUB 32        // units whose wave sums a block holds in LDS at a time (64 runs x 256 slices / 512 blocks)
 #define POCS_UNIT_SUMS 10      // survivors + the nine sums
 #define POCS_FLUSH_ROWS 5      // flush_unit's transpose scratch per wave: 5 rows of 64 lane values,

@@ -335,9 +335,14 @@ __device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, 
 // The whole advance to waypoint w by a block of >= 128 threads (every thread calls it).
 // staged: the caller has issued advance_stage already (and a barrier since); publish: state[w] / param[w] go out
 // to global memory as well (always, except for all but one block of a lone call's launch).
+struct advance_no_side_job { __device__ __forceinline__ void operator()() const {} };
+// `side_job`: run by the threads tid >= 128 -- the waves that otherwise wait at the barrier below for the components'
+// serial chain (wave 0) and the count lane (wave 1) -- with nothing of the advance's scratch in it (the lone form's
+// heads draw the first iterations' normals there, k_gmm_step)
+template <typename SideJob = advance_no_side_job>
 __device__ __forceinline__ void advance_block(const pocs_gmm_launch& a, int K, int w, int r, double* adv, double* spec,
                                               bool mom_in_lds, int tid, int nthreads, const bool staged = false,
-                                              const bool publish = true) {
+                                              const bool publish = true, SideJob side_job = SideJob()) {
   POCS_ADV_STAMP_BEGIN();
   if (!staged) {
     advance_stage(a, K, w, r, adv, mom_in_lds, tid, nthreads);
@@ -346,6 +351,7 @@ __device__ __forceinline__ void advance_block(const pocs_gmm_launch& a, int K, i
   POCS_ADV_STAMP(8);
   if (tid < 64) advance_components(a, K, w, r, tid, adv);
   else if (tid == 64 && w > 0) speculate_counts(a, K, w, r, adv, spec);
+  else if (tid >= 128) side_job();
   POCS_ADV_STAMP(9);
   __syncthreads();
   POCS_ADV_STAMP(10);
@@ -571,9 +577,12 @@ __device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, T
 // works through the units at its own pace and leaves its wave sums in LDS (flush_unit).  What a lane adds
 // up, and in which order, depends on (run, virtual slice, wave, lane) only.
 // ---------------------------------------------------------------------------------------------
-template <int K, bool STORE, int TB>
+//   zpre / npre (the lone form, LONE_PRE): the normals of the unit's first `npre` iterations, drawn in the block's head by
+//   the waves that waited there ([iteration][sample of the pair x 3][thread]); the same function of the same arguments,
+//   the same bits -- a call of one run then spends its sampling phase on what depends on the mixture only
+template <int K, bool STORE, int TB, bool LONE_PRE = false>
 __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm, const int w, const int r0,
-                                          const int ta, const int tb) {
+                                          const int ta, const int tb, const double* zpre = nullptr, const int npre = 0) {
   const pocs_tables* const s_tab = &sm.tab;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -617,6 +626,7 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
   // inside component block kw and inside the shard -- every lane live, both samples of its pair exist,
   // the component is the scalar kw == kcur.  Otherwise: the general case (a block boundary inside the
   // wave, the shard's last chunk), every decision per lane.  Same arithmetic per sample either way.
+  int it_unit = 0;                                  // (lone form) the iteration's number within the unit
   auto iteration = [&](auto whole_tag, const int base, const int tl, bool& first) __attribute__((always_inline)) {
     constexpr bool WHOLE = decltype(whole_tag)::value;
     switch (prio_it++ & 3) {                       // s_setprio takes an immediate
@@ -636,7 +646,19 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(seed_it));
 #endif
-    POCS_TUNE_NORMALS(pocs_normal3_pair(seed_it, pair0 + (uint64_t)(unsigned)lp, (uint32_t)w, POCS_STREAM_GMM, s_tab, zz[0], zz[1], &spare[0], &spare[1], vc));
+    bool drawn = false;
+    if constexpr (LONE_PRE) {
+      if (it_unit < npre) {                          // (scalar)
+        const double* z = zpre + (size_t)it_unit * 6 * TB + tid;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { zz[0][q] = z[q * TB]; zz[1][q] = z[(3 + q) * TB]; }
+        drawn = true;
+        ++it_unit;
+      }
+    }
+    if (!drawn) {
+      POCS_TUNE_NORMALS(pocs_normal3_pair(seed_it, pair0 + (uint64_t)(unsigned)lp, (uint32_t)w, POCS_STREAM_GMM, s_tab, zz[0], zz[1], &spare[0], &spare[1], vc));
+    }
     const int i0 = 2 * lp;
     const bool two = WHOLE || (live && (i0 + 1) < count);  // false only for the last sample of an odd shard
     double xs[2], ys[2], ts[2];
@@ -751,6 +773,7 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
     const int c_begin = (int)(((long long)j * a.chunks) >> a.vs_shift);
     const int c_end = (int)(((long long)(j + 1) * a.chunks) >> a.vs_shift);
     bool first = true;                               // (scalar) nothing of this unit has been flushed yet
+    it_unit = (t == ta) ? 0 : npre;                  // (lone form) normals drawn ahead exist for the first unit held only
     // A wave's samples only move forward within a run, so the component block found for an earlier unit still
     // holds while the wave's 128 samples end before seg_end; it is looked up again (a few vector compares)
     // only when they do not: at a block boundary, at the shard's end.
@@ -893,10 +916,13 @@ __device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const i
 // param[w] out for the getters.  The tail is the rows' stores and nothing else; a one-block launch
 // (k_gmm_close) adds the last waypoint's rows.  Same functions, same order of additions: the same bits.
 template <int K, bool STORE, int TB, bool LONE>
-__global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_step(pocs_gmm_launch a) {
+__global__ __launch_bounds__(TB, (LONE ? 1 : POCS_GMM_BLOCKS_PER_CU) * TB / 256) void k_gmm_step(pocs_gmm_launch a) {   // (lone: one block per CU, its LDS)
   typedef gmm_smem<K, TB> smem_t;
   constexpr int SUB = smem_t::SUB, NW = smem_t::NW;
   __shared__ smem_t sm;
+  // (lone form: one block per CU, the whole LDS is its own) the normals of the unit's first POCS_LONE_PRE iterations
+  __shared__ double s_zpre[LONE ? POCS_LONE_PRE * 6 * TB : 2];
+  int npre = 0;
   const int tid = threadIdx.x;
   const int w = a.waypoint;
   const int t_lo = a.run_lo << a.vs_shift, t_hi = (a.run_lo + a.run_cnt) << a.vs_shift;    // this launch's units
@@ -922,7 +948,27 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
     gmm_close_sums<K, TB>(a, w - 1, r0, sm.par[1], sm.stage(), l_mom, tid, a.partial_prev, out);   // ... with the rows'
     POCS_STAMP(5);
     if (tid < a.M * POCS_OBS_STRIDE) sm.obs()[tid] = obs_elem;      // (every read of the staging rows lies behind a barrier of gmm_close_sums)
-    advance_block(a, K, w, r0, sm.adv(), sm.spec(), true, tid, TB, true, out);
+    // While wave 0 walks the components' serial chain and a lane of wave 1 draws the counts, the other six waves draw
+    // the normals of the block's first unit -- they do not depend on the mixture -- for all 512 threads and the unit's
+    // first iterations: (seed, pair index, waypoint) -> six normals, the arguments the sampling loop would use.
+    const int j0 = t0 & ((1 << a.vs_shift) - 1);
+    const int cb0 = (int)(((long long)j0 * a.chunks) >> a.vs_shift), ce0 = (int)(((long long)(j0 + 1) * a.chunks) >> a.vs_shift);
+    npre = (ce0 - cb0) < POCS_LONE_PRE ? (ce0 - cb0) : POCS_LONE_PRE;
+    auto draw_ahead = [&]() __attribute__((always_inline)) {
+      POCS_VCONST(vc_);
+      const uint64_t seed = a.hdr[r0].seed;
+      const uint64_t pair0 = (uint64_t)(a.first >> 1);
+      for (int it = 0; it < npre; ++it)
+        for (int l = tid - 128; l < TB; l += TB - 128) {
+          double za[3], zb[3];
+          uint32_t sa, sb;
+          pocs_normal3_pair(seed, pair0 + (uint64_t)(unsigned)((cb0 + it) * TB + l), (uint32_t)w, POCS_STREAM_GMM, &sm.tab, za, zb, &sa, &sb, &vc_);
+          double* z = s_zpre + (size_t)it * 6 * TB + l;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { z[q * TB] = za[q]; z[(3 + q) * TB] = zb[q]; }
+        }
+    };
+    advance_block(a, K, w, r0, sm.adv(), sm.spec(), true, tid, TB, true, out, draw_ahead);
     __syncthreads();
     POCS_STAMP(6);
     POCS_STAMP_COUNT(14);
@@ -943,7 +989,7 @@ __global__ __launch_bounds__(TB, POCS_GMM_BLOCKS_PER_CU * TB / 256) void k_gmm_s
   POCS_STAMP(0);
   for (int ta = t0; ta < t1; ta += SUB) {
     const int tb = (ta + SUB < t1) ? ta + SUB : t1;
-    gmm_units<K, STORE, TB>(a, sm, w, r0, ta, tb);
+    gmm_units<K, STORE, TB, LONE>(a, sm, w, r0, ta, tb, s_zpre, ta == t0 ? npre : 0);
     POCS_STAMP(1);
     __syncthreads();
     POCS_STAMP(2);
