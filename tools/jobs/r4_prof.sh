@@ -29,4 +29,6 @@ one r4d_cfg3 r04_d_cfg3 k_gmm_step "k_gmm_step<8, true" gmm 80000000 "python3 be
 # the same kernel with ONE launch of 20 runs per waypoint (POCS_SUB_BATCHES=1): the form in which a kernel trace's duration and the bench line's
 # span-timed period are the same quantity (with two sub-batches side by side the profiler keeps the twins from overlapping as they do alone)
 POCS_SUB_BATCHES=1 one r4e_d20 r04_e_driver20_single k_gmm_step "k_gmm_step<3, true" gmm 20000000 "POCS_SUB_BATCHES=1 python3 bench.py --steps 20 --warmup 5 (20 runs x 10^6 samples per waypoint, K=3, ONE launch per waypoint; numerics v9, the round's final kernel)" --steps 20 --warmup 5
+# one run per call: the lone form (every block closes the previous waypoint in its head and draws the first iterations' normals ahead)
+one r4f_lone r04_f_lone k_gmm_step "k_gmm_step<3, true, 512, true" gmm 1000000 "python3 bench.py --batch 1 --steps 16 --warmup 4 (one run per call, the lone launch form with the normals drawn ahead; numerics v9, end of round 4)" --batch 1 --steps 16 --warmup 4
 cp profiles/traffic.json gpurun_out/traffic_r04.json
