@@ -102,6 +102,10 @@ POCS_HD bool pocs_pose_collides(double x, double y, double th, const pocs_footpr
 // The same predicate for the two poses a thread of k_gmm_step draws per iteration, with ONE pass over the obstacle
 // table: every record is read once for both poses (the table sits in LDS), the loop's bookkeeping is paid once.
 // Per pose exactly the operations of pocs_pose_collides, in the same order: the same flags.
+//   EAGER (k_gmm_step's lone form, whose sampling phase is latency): a record's eight doubles are all requested at the
+//   head of its iteration and waited for once, instead of field by field as the tests get to them (three LDS round
+//   trips per pose where lanes reach the narrow phase)
+template <bool EAGER = false>
 POCS_HD void pocs_pair_collides(const double x[2], const double y[2], const double th[2], const pocs_footprint* fp,
                                 const double* obs, int M, const pocs_tables* T, const pocs_vconst* V, bool hit[2]) {
   hit[0] = false; hit[1] = false;
@@ -126,6 +130,13 @@ POCS_HD void pocs_pair_collides(const double x[2], const double y[2], const doub
   for (int m = 0; m < M; ++m) {
     const double* o = obs + m * POCS_OBS_STRIDE;
 #if defined(__HIP_DEVICE_COMPILE__)
+    double rec[POCS_OBS_STRIDE];
+    if (EAGER) {
+#pragma unroll
+      for (int q = 0; q < POCS_OBS_STRIDE; ++q) rec[q] = o[q];
+      asm volatile("" : "+v"(rec[0]), "+v"(rec[1]), "+v"(rec[2]), "+v"(rec[3]), "+v"(rec[4]), "+v"(rec[5]), "+v"(rec[6]), "+v"(rec[7]));
+      o = rec;
+    }
 #pragma unroll
 #endif
     // `if (...) hit = true`, not `hit |= ...`: the flag then stays a lane mask in scalar registers across the

@@ -683,7 +683,7 @@ __device__ __forceinline__ void gmm_units(const pocs_gmm_launch& a, gmm_smem<K, 
       ks[h] = k;
     }
     POCS_TUNE_COLLIDE_STATS();
-    POCS_TUNE_COLLIDE(pocs_pair_collides(xs, ys, ts, &fp, s_keep, nkeep, s_tab, vc, hits));
+    POCS_TUNE_COLLIDE(pocs_pair_collides<LONE_PRE>(xs, ys, ts, &fp, s_keep, nkeep, s_tab, vc, hits));
     if constexpr (POCS_TUNE_SKIP_MOMENTS) { POCS_TUNE_MOMENTS_ALT(); } else {
     // T1 sums over the collision-free samples of the component being accumulated:
     //   (x, y, t, x x, x y, x t, y y, y t, t t) with the products inside the fma; survivors by population count.
