@@ -89,6 +89,32 @@ __device__ __forceinline__ void stage_tables(const pocs_tables* __restrict__ g, 
     dst[j] = (j < NLG && (j & 1) == 0) ? 2.0 * src[j] : src[j];
 }
 
+// The same in two steps for a block of TB threads (k_gmm_step's heads): the loads, into registers -- and, once everything
+// else the head needs has been requested behind them, the stores.  (stage_tables' loop has a run-time stride: the
+// compiler keeps it a loop and waits for every load before it issues the next, three memory round trips one after the
+// other for 24 bytes per thread.)
+constexpr int POCS_TABLE_DOUBLES = (int)(sizeof(pocs_tables) / sizeof(double));
+template <int TB> struct table_regs { static constexpr int N = (POCS_TABLE_DOUBLES + TB - 1) / TB; };
+template <int TB>
+__device__ __forceinline__ void request_tables(const pocs_tables* __restrict__ g, const int tid, double (&v)[table_regs<TB>::N]) {
+  const double* src = reinterpret_cast<const double*>(g);
+#pragma unroll
+  for (int u = 0; u < table_regs<TB>::N; ++u) { const int j = tid + u * TB; v[u] = (j < POCS_TABLE_DOUBLES) ? src[j] : 0.0; }
+}
+template <int TB>
+__device__ __forceinline__ void commit_tables(pocs_tables* s_tab, const int tid, const double (&v)[table_regs<TB>::N]) {
+  double* dst = reinterpret_cast<double*>(s_tab);
+  constexpr int NLG = (int)(sizeof(s_tab->lg) / sizeof(double));
+#pragma unroll
+  for (int u = 0; u < table_regs<TB>::N; ++u) {
+    const int j = tid + u * TB;
+    if (j < POCS_TABLE_DOUBLES) dst[j] = (j < NLG && (j & 1) == 0) ? 2.0 * v[u] : v[u];
+  }
+}
+// everything requested so far is in flight before anything that follows is issued (loads do not sink below it, stores do
+// not rise above it): the head's requests, then ONE wait
+__device__ __forceinline__ void requests_issued() { asm volatile("" ::: "memory"); }
+
 // The MC kernels only evaluate the footprint heading: the 4 KB sector table is all they need.
 __device__ __forceinline__ void stage_sector_table(const pocs_tables* __restrict__ g, pocs_tables* s_tab) {
   const double* src = &g->sc[0][0];
@@ -254,35 +280,52 @@ __device__ __forceinline__ void stage_batched(double* stage, const int n, const 
 // has just reduced them); otherwise they are read from a.moments (own launch: after the caller's
 // all-reduce).  state[w-1] may have been written by another block of THIS launch: L1-bypassing loads.
 // One batch of loads for everything (the scratch is laid out l_prev | l_mom | l_ch | l_sen).
+// (request / commit: the batch of four loads per thread that starts at index i0, and their stores -- a caller with other
+// requests to make puts them between the two, so that all of them share one round trip)
+__device__ __forceinline__ int advance_stage_count(const adv_ptrs& p, const bool load_mom) {
+  constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
+  return p.ss + POCS_CHAIN_STRIDE + SEN + (load_mom ? p.NC : 0);
+}
+__device__ __forceinline__ void advance_request(const adv_ptrs& p, const bool load_mom, const int i0, const int nthreads, double (&v)[4]) {
+  constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
+  const int ss = p.ss, n = advance_stage_count(p, load_mom);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = i0 + u * nthreads;
+    v[u] = 0.0;
+    if (i < ss) v[u] = load_wt(&p.g_prev[i]);
+    else if (i < ss + POCS_CHAIN_STRIDE) v[u] = p.g_ch[i - ss];
+    else if (i < ss + POCS_CHAIN_STRIDE + SEN) v[u] = p.g_sen[i - ss - POCS_CHAIN_STRIDE];
+    else if (i < n) v[u] = p.g_mom[i - ss - POCS_CHAIN_STRIDE - SEN];
+  }
+}
+__device__ __forceinline__ void advance_commit(const adv_ptrs& p, const bool load_mom, const int i0, const int nthreads, const double (&v)[4]) {
+  constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
+  const int ss = p.ss, n = advance_stage_count(p, load_mom);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = i0 + u * nthreads;
+    if (i < ss) p.l_prev[i] = v[u];
+    else if (i < ss + POCS_CHAIN_STRIDE + SEN) p.l_ch[i - ss] = v[u];              // l_ch | l_sen are contiguous
+    else if (i < n) p.l_mom[i - ss - POCS_CHAIN_STRIDE - SEN] = v[u];
+  }
+}
 __device__ __forceinline__ void advance_stage(const pocs_gmm_launch& a, int K, int w, int r, double* scratch,
                                               bool mom_in_lds, int tid, int nthreads) {
   const adv_ptrs p = advance_ptrs(a, K, w, r, scratch);
-  constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
-  const int ss = p.ss, NC = p.NC;
   const bool load_mom = w > 0 && !mom_in_lds;
   // index space: [0, ss) state | [ss, ss + CH + SEN) chain record, sensor | then (only if wanted) the moments;
   // l_mom is NOT touched when the caller has put the moments there
-  const int n = ss + POCS_CHAIN_STRIDE + SEN + (load_mom ? NC : 0);
+  const int n = advance_stage_count(p, load_mom);
   for (int i0 = tid; i0 < n; i0 += nthreads * 4) {
     double v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * nthreads;
-      v[u] = 0.0;
-      if (i < ss) v[u] = load_wt(&p.g_prev[i]);
-      else if (i < ss + POCS_CHAIN_STRIDE) v[u] = p.g_ch[i - ss];
-      else if (i < ss + POCS_CHAIN_STRIDE + SEN) v[u] = p.g_sen[i - ss - POCS_CHAIN_STRIDE];
-      else if (i < n) v[u] = p.g_mom[i - ss - POCS_CHAIN_STRIDE - SEN];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * nthreads;
-      if (i < ss) p.l_prev[i] = v[u];
-      else if (i < ss + POCS_CHAIN_STRIDE + SEN) p.l_ch[i - ss] = v[u];              // l_ch | l_sen are contiguous
-      else if (i < n) p.l_mom[i - ss - POCS_CHAIN_STRIDE - SEN] = v[u];
-    }
+    advance_request(p, load_mom, i0, nthreads, v);
+    requests_issued();
+    advance_commit(p, load_mom, i0, nthreads, v);
   }
 }
+// the largest index space of advance_stage: a block of TB threads with 4 TB >= this stages it in ONE batch
+#define POCS_ADV_STAGE_MAX (POCS_MAX_GAUSSIANS * (POCS_STATE_STRIDE + POCS_NMOM) + POCS_CHAIN_STRIDE + (int)(sizeof(pocs_sensor) / sizeof(double)))
 
 // one wave, after advance_stage (+ barrier): one component per lane
 __device__ __forceinline__ void advance_components(const pocs_gmm_launch& a, int K, int w, int r, int lane, double* scratch) {
@@ -841,19 +884,14 @@ __device__ __forceinline__ void gmm_emit_rows(const pocs_gmm_launch& a, gmm_smem
 // this shard's samples: nColl_k = n_k - nFree_k, with [cum_{k-1}, cum_k) the component's global sample
 // range (par[k][9], cum_{K-1} = n_total).  Result: tot[c], and moments[w][r][c] in global memory (it
 // leaves the launch at the kernel boundary).
+// The rows of ONE batch of work items (two per thread, starting at item i0): request() issues every load, reduce() adds
+// them in row order into the staging rows.  A caller with other requests to make (the lone form's heads; the closer, whose
+// mixture advance wants state[w] and the chain record) issues the first batch itself, next to them.
 template <int K, int NT>
-__device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const int w, const int r, const double* s_par,
-                                               double* stage, double* tot, const int tid,
-                                               const double* rows, const bool store) {
-  constexpr int NC = K * POCS_NMOM, G = 16, ITEMS = G * NC, RPI = POCS_GMM_MAX_VS / G, nthreads = NT;
-  const int S = 1 << a.vs_shift;
-  const double* src = rows + (size_t)r * S * NC;
-  // An item's (up to) sixteen rows g, g + 16, ... are all requested before the first is waited for, and so are the
-  // rows of the thread's NEXT item where there are more items than threads (K = 3: 528 items on 512 threads --
-  // taken one after the other, sixteen threads cost the whole block a second memory round trip): two items per
-  // batch, ONE round trip per batch for the run's 256 rows.  Added in row order.
-  for (int i0 = tid; i0 < ITEMS; i0 += 2 * NT) {
-    double v[2][RPI];
+struct close_rows {
+  static constexpr int NC = K * POCS_NMOM, G = 16, ITEMS = G * NC, RPI = POCS_GMM_MAX_VS / G;
+  double v[2][RPI];
+  __device__ __forceinline__ void request(const double* src, const int S, const int i0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int i = i0 + t * NT, g = i / NC, c = i - g * NC;
@@ -863,6 +901,18 @@ __device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const i
         v[t][u] = (i < ITEMS && q < S) ? load_wt(&src[(size_t)q * NC + c]) : 0.0;
       }
     }
+  }
+  // every value passes through an (empty) asm statement: the additions of reduce() cannot rise above it into the branches
+  // of the loads -- where the compiler, left to itself, puts an item's first one, with a wait for that load in front of
+  // all the others
+  __device__ __forceinline__ void pin() {
+    static_assert(RPI % 4 == 0, "four values per statement");
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < RPI; u += 4) asm volatile("" : "+v"(v[t][u]), "+v"(v[t][u + 1]), "+v"(v[t][u + 2]), "+v"(v[t][u + 3]));
+  }
+  __device__ __forceinline__ void reduce(double* stage, const int S, const int i0) const {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int i = i0 + t * NT, g = i / NC;
@@ -871,6 +921,31 @@ __device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const i
       for (int u = 0; u < RPI; ++u) if (g + u * G < S) sum += v[t][u];
       if (i < ITEMS) stage[i] = sum;
     }
+  }
+};
+template <int K>
+__device__ __forceinline__ const double* close_rows_of(const pocs_gmm_launch& a, const double* rows, const int r) {
+  return rows + (size_t)r * (1 << a.vs_shift) * (K * POCS_NMOM);
+}
+//   REQUESTED: the caller has issued the first batch (items tid, tid + NT) into `cr` already
+template <int K, int NT, bool REQUESTED = false>
+__device__ __forceinline__ void gmm_close_sums(const pocs_gmm_launch& a, const int w, const int r, const double* s_par,
+                                               double* stage, double* tot, const int tid,
+                                               const double* rows, const bool store, close_rows<K, NT>& cr) {
+  constexpr int NC = K * POCS_NMOM, G = 16, ITEMS = G * NC, nthreads = NT;
+  const int S = 1 << a.vs_shift;
+  const double* src = close_rows_of<K>(a, rows, r);
+  // An item's (up to) sixteen rows g, g + 16, ... are all requested before the first is waited for, and so are the
+  // rows of the thread's NEXT item where there are more items than threads (K = 3: 528 items on 512 threads --
+  // taken one after the other, sixteen threads cost the whole block a second memory round trip): two items per
+  // batch, ONE round trip per batch for the run's 256 rows.  Added in row order.  (requests_issued() between the two
+  // steps: left to itself the compiler folds an item's first addition into the branch of its first load and waits
+  // there -- three round trips per batch instead of one.)
+  for (int i0 = tid; i0 < ITEMS; i0 += 2 * NT) {
+    if (!(REQUESTED && i0 == tid)) cr.request(src, S, i0);
+    requests_issued();
+    cr.pin();
+    cr.reduce(stage, S, i0);
   }
   __syncthreads();
   for (int c = tid; c < NC; c += nthreads) {
@@ -931,21 +1006,35 @@ __global__ __launch_bounds__(TB, (LONE ? 1 : POCS_GMM_BLOCKS_PER_CU) * TB / 256)
   const int t1 = (t0 + a.upb < t_hi) ? t0 + a.upb : t_hi;
   const int r0 = t0 >> a.vs_shift, r1 = (t1 - 1) >> a.vs_shift;       // the block's first and last run (r1 <= r0 + 1)
   POCS_STAMP_BEGIN();
-  stage_tables(a.tables, &sm.tab);
+  // The head's inputs are all REQUESTED before the first of them is waited for: the tables (24 bytes per thread), and per
+  // form what follows -- one memory round trip for the lot, then the stores to LDS.
+  constexpr int PS = K * POCS_PARAM_STRIDE;
+  static_assert(POCS_MAX_OBSTACLES * POCS_OBS_STRIDE <= TB, "one obstacle element per thread");
+  static_assert(2 * PS <= TB, "one sampler parameter per thread (two runs)");
+  static_assert(POCS_ADV_STAGE_MAX <= 4 * TB, "the advance's inputs in one batch");
+  double tabv[table_regs<TB>::N];
+  request_tables<TB>(a.tables, tid, tabv);
+  const double obs_elem = tid < a.M * POCS_OBS_STRIDE ? a.env->obs[tid] : 0.0;
   if (LONE && w > 0) {
     // close waypoint w - 1 and advance to w, here (r0 is the call's one run)
-    constexpr int PS = K * POCS_PARAM_STRIDE;
     const bool out = blockIdx.x == 0;
-    advance_stage(a, K, w, r0, sm.adv(), true, tid, TB);                                   // loads in flight ...
-    for (int j = tid; j < PS; j += TB) sm.par[1][j] = a.param[((size_t)r0 * a.W + (w - 1)) * PS + j];   // (the counts of w - 1)
+    const adv_ptrs ap = advance_ptrs(a, K, w, r0, sm.adv());
+    double advv[4];
+    advance_request(ap, false, tid, TB, advv);                                             // state[w-1], chain record, sensor (the moments come from the rows)
+    const double parv = tid < PS ? a.param[((size_t)r0 * a.W + (w - 1)) * PS + tid] : 0.0;   // (the counts of w - 1)
+    const unsigned long long seedv = a.hdr[r0].seed;
+    close_rows<K, TB> cr;
+    cr.request(close_rows_of<K>(a, a.partial_prev, r0), 1 << a.vs_shift, tid);             // the rows of w - 1
+    requests_issued();
+    commit_tables<TB>(&sm.tab, tid, tabv);
+    advance_commit(ap, false, tid, TB, advv);
+    if (tid < PS) sm.par[1][tid] = parv;
     for (int j = tid; j < 2 * NW * K; j += TB) (&sm.xj[0][0][0])[j] = -1;
-    if (tid == 0) sm.seed[0] = a.hdr[r0].seed;
-    double* const l_mom = advance_ptrs(a, K, w, r0, sm.adv()).l_mom;
+    if (tid == 0) sm.seed[0] = seedv;
+    double* const l_mom = ap.l_mom;
     // (the obstacle table, one element per thread, requested with everything else: it lands in the transpose scratch as soon
     // as the row sums are done with it, under the components' serial chain instead of in a round trip of its own behind it)
-    static_assert(POCS_MAX_OBSTACLES * POCS_OBS_STRIDE <= TB, "one obstacle element per thread");
-    const double obs_elem = tid < a.M * POCS_OBS_STRIDE ? a.env->obs[tid] : 0.0;
-    gmm_close_sums<K, TB>(a, w - 1, r0, sm.par[1], sm.stage(), l_mom, tid, a.partial_prev, out);   // ... with the rows'
+    gmm_close_sums<K, TB, true>(a, w - 1, r0, sm.par[1], sm.stage(), l_mom, tid, a.partial_prev, out, cr);
     POCS_STAMP(5);
     if (tid < a.M * POCS_OBS_STRIDE) sm.obs()[tid] = obs_elem;      // (every read of the staging rows lies behind a barrier of gmm_close_sums)
     // While wave 0 walks the components' serial chain and a lane of wave 1 draws the counts, the other six waves draw
@@ -956,7 +1045,7 @@ __global__ __launch_bounds__(TB, (LONE ? 1 : POCS_GMM_BLOCKS_PER_CU) * TB / 256)
     npre = (ce0 - cb0) < POCS_LONE_PRE ? (ce0 - cb0) : POCS_LONE_PRE;
     auto draw_ahead = [&]() __attribute__((always_inline)) {
       POCS_VCONST(vc_);
-      const uint64_t seed = a.hdr[r0].seed;
+      const uint64_t seed = seedv;                          // (requested with the head's other inputs)
       const uint64_t pair0 = (uint64_t)(a.first >> 1);
       for (int it = 0; it < npre; ++it)
         for (int l = tid - 128; l < TB; l += TB - 128) {
@@ -975,12 +1064,16 @@ __global__ __launch_bounds__(TB, (LONE ? 1 : POCS_GMM_BLOCKS_PER_CU) * TB / 256)
     const double* const l_par = advance_ptrs(a, K, w, r0, sm.adv()).l_par;
     for (int j = tid; j < PS; j += TB) sm.par[0][j] = l_par[j];
   } else {
-    for (int j = tid; j < a.M * POCS_OBS_STRIDE; j += TB) sm.obs()[j] = a.env->obs[j];
-    for (int j = tid; j < (r1 - r0 + 1) * K * POCS_PARAM_STRIDE; j += TB)   // param[r][w][..]: the two runs' records are a.W records apart
-      sm.par[j / (K * POCS_PARAM_STRIDE)][j % (K * POCS_PARAM_STRIDE)] =
-          load_wt(&a.param[((size_t)(r0 + j / (K * POCS_PARAM_STRIDE)) * a.W + w) * (K * POCS_PARAM_STRIDE) + j % (K * POCS_PARAM_STRIDE)]);
+    // param[r][w][..]: the two runs' records are a.W records apart
+    const int rp = tid / PS, jp = tid - rp * PS;
+    const double parv = tid < (r1 - r0 + 1) * PS ? load_wt(&a.param[((size_t)(r0 + rp) * a.W + w) * PS + jp]) : 0.0;
+    const unsigned long long seedv = tid <= r1 - r0 ? a.hdr[r0 + tid].seed : 0ull;
+    requests_issued();
+    commit_tables<TB>(&sm.tab, tid, tabv);
+    if (tid < a.M * POCS_OBS_STRIDE) sm.obs()[tid] = obs_elem;
+    if (tid < (r1 - r0 + 1) * PS) sm.par[rp][jp] = parv;
     for (int j = tid; j < 2 * NW * K; j += TB) (&sm.xj[0][0][0])[j] = -1;
-    if (tid <= r1 - r0) sm.seed[tid] = a.hdr[r0 + tid].seed;
+    if (tid <= r1 - r0) sm.seed[tid] = seedv;
   }
   __syncthreads();
   if (tid < 64) gmm_cull(a, sm, 0, tid);
@@ -1022,8 +1115,17 @@ __global__ __launch_bounds__(TB, (LONE ? 1 : POCS_GMM_BLOCKS_PER_CU) * TB / 256)
     const int r = r0 + rb;
     if (tid == 0) acquire_agent();
     __syncthreads();
-    double* const l_mom = advance_ptrs(a, K, w + 1, r, sm.adv()).l_mom;
-    gmm_close_sums<K, TB>(a, w, r, sm.par[rb], sm.stage(), l_mom, tid, a.partial, true);
+    // the run's rows and -- one GPU -- what the mixture advance wants besides their sums (state[w], the chain record, the
+    // sensor: written by earlier launches), requested together: one round trip instead of one after the other
+    const adv_ptrs ap = advance_ptrs(a, K, w + 1, r, sm.adv());
+    double* const l_mom = ap.l_mom;
+    double advv[4];
+    if (a.advance_in_tail) advance_request(ap, false, tid, TB, advv);
+    close_rows<K, TB> cr;
+    cr.request(close_rows_of<K>(a, a.partial, r), 1 << a.vs_shift, tid);
+    requests_issued();
+    if (a.advance_in_tail) advance_commit(ap, false, tid, TB, advv);
+    gmm_close_sums<K, TB, true>(a, w, r, sm.par[rb], sm.stage(), l_mom, tid, a.partial, true, cr);
     POCS_STAMP(5);
     if (a.exchange_in_tail) {
       // sharded: the run's closer is also its messenger -- this shard's moments go to every rank, the world's
@@ -1040,8 +1142,9 @@ __global__ __launch_bounds__(TB, (LONE ? 1 : POCS_GMM_BLOCKS_PER_CU) * TB / 256)
         parity = (int)((calls * (unsigned long long)a.W + (unsigned long long)w) & 1ull);
       }
       if (!gmm_exchange_rows(a, a.xchg, epoch, parity, K, w, r, l_mom, l_mom, tid, TB, &sm.nkeep[0] /* free by now */)) return false;
+      __syncthreads();                                 // the world's sums are in l_mom for the advance (which no longer starts with a staging barrier)
     }
-    if (a.advance_in_tail) advance_block(a, K, w + 1, r, sm.adv(), sm.spec(), true, tid, TB);     // starts with a barrier after staging
+    if (a.advance_in_tail) advance_block(a, K, w + 1, r, sm.adv(), sm.spec(), true, tid, TB, true);     // (staged above; gmm_close_sums' barriers lie between)
     __syncthreads();
     POCS_STAMP(6);
     POCS_STAMP_COUNT(14);
@@ -1061,7 +1164,8 @@ __global__ __launch_bounds__(256) void k_gmm_close(pocs_gmm_launch a) {
   __shared__ double s_tot[NC];
   const int w = a.waypoint, r = a.run_lo;
   for (int j = threadIdx.x; j < PS; j += 256) s_par[j] = a.param[((size_t)r * a.W + w) * PS + j];
-  gmm_close_sums<K, 256>(a, w, r, s_par, s_stage, s_tot, threadIdx.x, a.partial, true);    // (first barrier: s_par is in)
+  close_rows<K, 256> cr;
+  gmm_close_sums<K, 256>(a, w, r, s_par, s_stage, s_tot, threadIdx.x, a.partial, true, cr);    // (first barrier: s_par is in)
 }
 
 // MC kernels: blockIdx.y = run of the batch (its own seed, its own noisy controls, its own slice
