@@ -155,19 +155,32 @@ POCS_HD void pocs_pair_collides(const double x[2], const double y[2], const doub
 //   rr = the bounding radius sqrt(rx^2 + ry^2), phi = atan2(ry, rx): constants of the footprint, computed once on the
 //   host for the kernels (every block of every launch culls: a square root, an arc tangent and four divisions less
 //   in each of them)
-POCS_HD double pocs_footprint_extent_pre(double rx, double ry, double rr, double phi, double lo, double hi) {
+// (in three steps, so that a wave can evaluate the end values of several ranges side by side, one per lane: gmm_cull)
+//   is the bounding radius the answer without looking at the ends (a range of pi or more, a peak inside it)?
+POCS_HD bool pocs_footprint_extent_is_radius(double phi, double lo, double hi) {
   const double PI = 3.14159265358979323846, INV_PI = 0.318309886183790671538;
-  if (!(hi - lo < PI)) return rr;
+  if (!(hi - lo < PI)) return true;
   for (int sgn = -1; sgn <= 1; sgn += 2) {
     const double s = sgn * phi;
-    if (ceil((lo - s) * INV_PI) <= floor((hi - s) * INV_PI)) return rr;   // a peak inside the range
+    if (ceil((lo - s) * INV_PI) <= floor((hi - s) * INV_PI)) return true;   // a peak inside the range
   }
+  return false;
+}
+//   f at one end of a range
+POCS_HD double pocs_footprint_extent_end(double rx, double ry, double t) {
   double sn, cs;
-  pocs_sincos(lo, &sn, &cs);
-  const double fa = fma(rx, fabs(cs), ry * fabs(sn));
-  pocs_sincos(hi, &sn, &cs);
-  const double fb = fma(rx, fabs(cs), ry * fabs(sn));
+  pocs_sincos(t, &sn, &cs);
+  return fma(rx, fabs(cs), ry * fabs(sn));
+}
+//   the bound from the two end values
+POCS_HD double pocs_footprint_extent_of_ends(double rr, double fa, double fb) {
   return fmin(rr, fmax(fa, fb) * (1.0 + 1e-9) + 1e-12);
+}
+POCS_HD double pocs_footprint_extent_pre(double rx, double ry, double rr, double phi, double lo, double hi) {
+  if (pocs_footprint_extent_is_radius(phi, lo, hi)) return rr;
+  const double fa = pocs_footprint_extent_end(rx, ry, lo);
+  const double fb = pocs_footprint_extent_end(rx, ry, hi);
+  return pocs_footprint_extent_of_ends(rr, fa, fb);
 }
 POCS_HD double pocs_footprint_extent(double rx, double ry, double lo, double hi) {
   return pocs_footprint_extent_pre(rx, ry, sqrt(rx * rx + ry * ry), atan2(ry, rx), lo, hi);
