@@ -115,19 +115,31 @@ __device__ __forceinline__ void commit_tables(pocs_tables* s_tab, const int tid,
 // not rise above it): the head's requests, then ONE wait
 __device__ __forceinline__ void requests_issued() { asm volatile("" ::: "memory"); }
 
-// The MC kernels only evaluate the footprint heading: the 4 KB sector table is all they need.
-__device__ __forceinline__ void stage_sector_table(const pocs_tables* __restrict__ g, pocs_tables* s_tab) {
+// The head of an MC block (POCS_BLOCK threads): the collision world (obstacle records, footprint, M) and the 4 KB sector table --
+// the MC kernels only evaluate the footprint heading -- into LDS.  Every load is issued before the first is waited for: written
+// as copy loops with the block size as their stride, the compiler kept them loops of load - wait - store, four dependent
+// memory round trips in front of every block's first particle.  (The obstacle array has its full size whatever M is: all of
+// it is requested, M need not be known first.)
+__device__ __forceinline__ void stage_mc_head(const pocs_env_dev* __restrict__ env, const pocs_tables* __restrict__ g, double* s_obs,
+                                              pocs_footprint* s_fp, int* s_M, pocs_tables* s_tab) {
+  constexpr int NO = POCS_MAX_OBSTACLES * POCS_OBS_STRIDE, NS = (int)(sizeof(g->sc) / sizeof(double));
+  constexpr int UO = (NO + POCS_BLOCK - 1) / POCS_BLOCK, US = (NS + POCS_BLOCK - 1) / POCS_BLOCK;
+  const int tid = threadIdx.x;
   const double* src = &g->sc[0][0];
-  double* dst = &s_tab->sc[0][0];
-  for (int j = threadIdx.x; j < (int)(sizeof(g->sc) / sizeof(double)); j += blockDim.x) dst[j] = src[j];
-}
-
-// Stage the collision world into LDS.  s_obs must hold POCS_MAX_OBSTACLES*POCS_OBS_STRIDE doubles.
-__device__ __forceinline__ void stage_env(const pocs_env_dev* __restrict__ env, double* s_obs,
-                                          pocs_footprint* s_fp, int* s_M) {
+  double vo[UO], vs[US];
+#pragma unroll
+  for (int u = 0; u < UO; ++u) { const int i = tid + u * POCS_BLOCK; vo[u] = i < NO ? env->obs[i] : 0.0; }
+#pragma unroll
+  for (int u = 0; u < US; ++u) { const int i = tid + u * POCS_BLOCK; vs[u] = i < NS ? src[i] : 0.0; }
+  const pocs_footprint fp = env->fp;
   const int M = env->M;
-  for (int i = threadIdx.x; i < M * POCS_OBS_STRIDE; i += blockDim.x) s_obs[i] = env->obs[i];
-  if (threadIdx.x == 0) { *s_fp = env->fp; *s_M = M; }
+  asm volatile("" ::: "memory");                    // (requests_issued, defined further down)
+  double* dst = &s_tab->sc[0][0];
+#pragma unroll
+  for (int u = 0; u < UO; ++u) { const int i = tid + u * POCS_BLOCK; if (i < NO) s_obs[i] = vo[u]; }
+#pragma unroll
+  for (int u = 0; u < US; ++u) { const int i = tid + u * POCS_BLOCK; if (i < NS) dst[i] = vs[u]; }
+  if (tid == 0) { *s_fp = fp; *s_M = M; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1205,8 +1217,7 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_init(pocs_mc_launch a) {
   __shared__ pocs_footprint s_fp;
   __shared__ int s_M;
   __shared__ pocs_tables s_tab;
-  stage_env(a.env, s_obs, &s_fp, &s_M);
-  stage_sector_table(a.tables, &s_tab);
+  stage_mc_head(a.env, a.tables, s_obs, &s_fp, &s_M, &s_tab);
   __syncthreads();
   const mc_run_view v = mc_view(a);
   const pocs_footprint fp = s_fp;
@@ -1234,8 +1245,7 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_step(pocs_mc_launch a) {
   __shared__ pocs_footprint s_fp;
   __shared__ int s_M;
   __shared__ pocs_tables s_tab;
-  stage_env(a.env, s_obs, &s_fp, &s_M);
-  stage_sector_table(a.tables, &s_tab);
+  stage_mc_head(a.env, a.tables, s_obs, &s_fp, &s_M, &s_tab);
   __syncthreads();
   const mc_run_view v = mc_view(a);
   const pocs_footprint fp = s_fp;
@@ -1266,8 +1276,7 @@ __global__ __launch_bounds__(POCS_BLOCK) void k_mc_fused(pocs_mc_launch a) {
   __shared__ pocs_footprint s_fp;
   __shared__ int s_M;
   __shared__ pocs_tables s_tab;
-  stage_env(a.env, s_obs, &s_fp, &s_M);
-  stage_sector_table(a.tables, &s_tab);
+  stage_mc_head(a.env, a.tables, s_obs, &s_fp, &s_M, &s_tab);
   __syncthreads();
   const mc_run_view v = mc_view(a);
   const pocs_footprint fp = s_fp;
