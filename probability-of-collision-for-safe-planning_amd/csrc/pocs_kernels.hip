@@ -305,17 +305,31 @@ __device__ __forceinline__ int advance_stage_count(const adv_ptrs& p, const bool
   constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
   return p.ss + POCS_CHAIN_STRIDE + SEN + (load_mom ? p.NC : 0);
 }
-__device__ __forceinline__ void advance_request(const adv_ptrs& p, const bool load_mom, const int i0, const int nthreads, double (&v)[4]) {
+//   ONE_LOAD: one load per element, its address chosen by the element's range, L1-bypassing for all four sources (state[w-1]
+//   needs it, the others do not mind) -- for the closer, where around four different loads in an if / else-if chain the compiler
+//   put a wait behind each branch (three dependent round trips); the lone form's heads keep the chain (no waits there, and the
+//   chain record and the sensor come through the caches: measured 0.17 us per waypoint)
+template <bool ONE_LOAD = false>
+__device__ __forceinline__ void advance_request(const adv_ptrs& p, const bool load_mom, const int i0, const int nthreads, double (&v)[4],
+                                                const bool wanted = true) {
   constexpr int SEN = (int)(sizeof(pocs_sensor) / sizeof(double));
-  const int ss = p.ss, n = advance_stage_count(p, load_mom);
+  const int ss = p.ss, n = wanted ? advance_stage_count(p, load_mom) : 0;     // (not wanted: no lane loads anything -- and no branch round the loads)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int i = i0 + u * nthreads;
-    v[u] = 0.0;
-    if (i < ss) v[u] = load_wt(&p.g_prev[i]);
-    else if (i < ss + POCS_CHAIN_STRIDE) v[u] = p.g_ch[i - ss];
-    else if (i < ss + POCS_CHAIN_STRIDE + SEN) v[u] = p.g_sen[i - ss - POCS_CHAIN_STRIDE];
-    else if (i < n) v[u] = p.g_mom[i - ss - POCS_CHAIN_STRIDE - SEN];
+    if (ONE_LOAD) {
+      const double* src = i < ss ? &p.g_prev[i]
+                        : i < ss + POCS_CHAIN_STRIDE ? &p.g_ch[i - ss]
+                        : i < ss + POCS_CHAIN_STRIDE + SEN ? &p.g_sen[i - ss - POCS_CHAIN_STRIDE]
+                        : &p.g_mom[i - ss - POCS_CHAIN_STRIDE - SEN];
+      v[u] = i < n ? load_wt(src) : 0.0;
+    } else {
+      v[u] = 0.0;
+      if (i < ss) v[u] = load_wt(&p.g_prev[i]);
+      else if (i < ss + POCS_CHAIN_STRIDE) v[u] = p.g_ch[i - ss];
+      else if (i < ss + POCS_CHAIN_STRIDE + SEN) v[u] = p.g_sen[i - ss - POCS_CHAIN_STRIDE];
+      else if (i < n) v[u] = p.g_mom[i - ss - POCS_CHAIN_STRIDE - SEN];
+    }
   }
 }
 __device__ __forceinline__ void advance_commit(const adv_ptrs& p, const bool load_mom, const int i0, const int nthreads, const double (&v)[4]) {
@@ -1146,7 +1160,7 @@ __global__ __launch_bounds__(TB, (LONE ? 1 : POCS_GMM_BLOCKS_PER_CU) * TB / 256)
     const adv_ptrs ap = advance_ptrs(a, K, w + 1, r, sm.adv());
     double* const l_mom = ap.l_mom;
     double advv[4];
-    if (a.advance_in_tail) advance_request(ap, false, tid, TB, advv);
+    advance_request<true>(ap, false, tid, TB, advv, a.advance_in_tail != 0);
     close_rows<K, TB> cr;
     cr.request(close_rows_of<K>(a, a.partial, r), 1 << a.vs_shift, tid);
     requests_issued();
