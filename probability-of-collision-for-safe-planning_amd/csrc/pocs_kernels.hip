@@ -508,12 +508,21 @@ __device__ __forceinline__ bool gmm_exchange_rows(const pocs_gmm_launch& a, cons
   }
   __syncthreads();
   if (!*s_ok) return false;
-  // the slots of my buffer, added in rank order
+  // the slots of my buffer, added in rank order -- every rank's value REQUESTED before the first is waited for (as a loop over
+  // the world with the addition in it, the compiler waits for each system-scope load before it issues the next: eight
+  // dependent round trips per waypoint on eight GPUs)
   for (int c = tid; c < NC; c += nthreads) {
+    double v[POCS_XCHG_MAX_WORLD];
+#pragma unroll
+    for (int q = 0; q < POCS_XCHG_MAX_WORLD; ++q)
+      v[q] = q < x.world ? __longlong_as_double((long long)__hip_atomic_load(
+                 reinterpret_cast<const unsigned long long*>(xchg_row(x.buf[x.rank], parity, q, r) + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+                         : 0.0;
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    static_assert(POCS_XCHG_MAX_WORLD == 8, "eight values pinned");
     double tot = 0.0;
-    for (int q = 0; q < x.world; ++q)
-      tot += __longlong_as_double((long long)__hip_atomic_load(
-          reinterpret_cast<const unsigned long long*>(xchg_row(x.buf[x.rank], parity, q, r) + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+#pragma unroll
+    for (int q = 0; q < POCS_XCHG_MAX_WORLD; ++q) if (q < x.world) tot += v[q];
     a.moments[((size_t)w * a.nruns + r) * NC + c] = tot;    // the mixture's moments replace this shard's
     l_mom[c] = tot;
   }
