@@ -415,10 +415,13 @@ struct advance_no_side_job { __device__ __forceinline__ void operator()() const 
 // `side_job`: run by the threads tid >= 128 -- the waves that otherwise wait at the barrier below for the components'
 // serial chain (wave 0) and the count lane (wave 1) -- with nothing of the advance's scratch in it (the lone form's
 // heads draw the first iterations' normals there, k_gmm_step)
-template <typename SideJob = advance_no_side_job>
+// `post_job`: run by wave 1 (64 <= tid < 128; its lane 0 has drawn the counts by then) beside advance_finish, with nothing in it
+// that the normalisation still changes -- means and Cholesky factors of param[w] are final once the components are through
+// (the lone form's heads cull the obstacle table there)
+template <typename SideJob = advance_no_side_job, typename PostJob = advance_no_side_job>
 __device__ __forceinline__ void advance_block(const pocs_gmm_launch& a, int K, int w, int r, double* adv, double* spec,
                                               bool mom_in_lds, int tid, int nthreads, const bool staged = false,
-                                              const bool publish = true, SideJob side_job = SideJob()) {
+                                              const bool publish = true, SideJob side_job = SideJob(), PostJob post_job = PostJob()) {
   POCS_ADV_STAMP_BEGIN();
   if (!staged) {
     advance_stage(a, K, w, r, adv, mom_in_lds, tid, nthreads);
@@ -432,6 +435,7 @@ __device__ __forceinline__ void advance_block(const pocs_gmm_launch& a, int K, i
   __syncthreads();
   POCS_ADV_STAMP(10);
   if (tid < 64) advance_finish(a, K, w, r, tid, adv, w > 0 ? spec : nullptr, publish);
+  else if (tid < 128) post_job();
   POCS_ADV_STAMP(11);
 }
 __global__ __launch_bounds__(128) void k_gmm_advance(pocs_gmm_launch a, int K) {
@@ -614,14 +618,14 @@ __device__ __forceinline__ void flush_unit(gmm_smem<K, TB>& sm, const int wave, 
 // narrow phase, and none that could touch is lost: the flags do not change.
 //   (pocs_footprint_extent, pocs_collide.h: host + device, checked on the CPU against a dense scan)
 template <int K, int TB>
-__device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm, const int rb, const int lane) {
+__device__ __forceinline__ void gmm_cull(const pocs_gmm_launch& a, gmm_smem<K, TB>& sm, const int rb, const int lane, const double* par) {
   const pocs_footprint fp = a.fp;
   const int M = a.M;
   const double* const obs = sm.obs();
   double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300, tlo = 1e300, thi = -1e300;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const double* p = &sm.par[rb][k * POCS_PARAM_STRIDE];
+    const double* p = &par[k * POCS_PARAM_STRIDE];
     const double ex = 6.67 * fabs(p[3]), ey = 6.67 * (fabs(p[4]) + fabs(p[5])), et = 6.67 * (fabs(p[6]) + fabs(p[7]) + fabs(p[8]));
     xlo = fmin(xlo, p[0] - ex); xhi = fmax(xhi, p[0] + ex);
     ylo = fmin(ylo, p[1] - ey); yhi = fmax(yhi, p[1] + ey);
@@ -1106,7 +1110,10 @@ __global__ __launch_bounds__(TB, (LONE ? 1 : POCS_GMM_BLOCKS_PER_CU) * TB / 256)
           for (int q = 0; q < 3; ++q) { z[q * TB] = za[q]; z[(3 + q) * TB] = zb[q]; }
         }
     };
-    advance_block(a, K, w, r0, sm.adv(), sm.spec(), true, tid, TB, true, out, draw_ahead);
+    // (the cull of the obstacle table against the mixture of waypoint w -- means and factors only -- by wave 1, beside wave 0's
+    // normalisation and publishing instead of behind them and a barrier)
+    auto cull_early = [&]() __attribute__((always_inline)) { gmm_cull(a, sm, 0, tid - 64, ap.l_par); };
+    advance_block(a, K, w, r0, sm.adv(), sm.spec(), true, tid, TB, true, out, draw_ahead, cull_early);
     __syncthreads();
     POCS_STAMP(6);
     POCS_STAMP_COUNT(14);
@@ -1125,9 +1132,11 @@ __global__ __launch_bounds__(TB, (LONE ? 1 : POCS_GMM_BLOCKS_PER_CU) * TB / 256)
     if (tid <= r1 - r0) sm.seed[tid] = seedv;
   }
   __syncthreads();
-  if (tid < 64) gmm_cull(a, sm, 0, tid);
-  else if (tid < 128 && r1 > r0) gmm_cull(a, sm, 1, tid - 64);
-  __syncthreads();                                   // from here on the transpose scratch is the waves'
+  if (!(LONE && w > 0)) {                            // (scalar; the lone form's heads have culled already, above)
+    if (tid < 64) gmm_cull(a, sm, 0, tid, sm.par[0]);
+    else if (tid < 128 && r1 > r0) gmm_cull(a, sm, 1, tid - 64, sm.par[1]);
+    __syncthreads();
+  }                                                  // from here on the transpose scratch is the waves'
   POCS_STAMP(0);
   for (int ta = t0; ta < t1; ta += SUB) {
     const int tb = (ta + SUB < t1) ? ta + SUB : t1;
