@@ -114,3 +114,28 @@ def test_lone_form_has_no_handoff_inside_the_launch(listing, sub):
     assert not [o for o in ops if o.startswith("buffer_inv")], "an acquire in the lone form"
     assert not mem_ops(ops, "flat_"), "flat accesses in a GMM kernel"
     assert not [o for o in ops if o.startswith("s_sleep")], "a wait loop in the lone form"
+
+
+def _longest_run_of_loads(ops):
+    """The longest stretch of global loads with no wait for memory (`s_waitcnt vmcnt`) inside it."""
+    best = cur = 0
+    for o in ops:
+        if o.startswith("global_load"):
+            cur += 1
+            best = max(best, cur)
+        elif o.startswith("s_waitcnt") and "vmcnt" in o:
+            cur = 0
+    return best
+
+
+@pytest.mark.parametrize("sub,least", [("k_gmm_stepILi3ELb1ELi512ELb1E", 32), ("k_gmm_stepILi8ELb1ELi512ELb1E", 32),
+                                       ("k_gmm_stepILi3ELb1ELi512ELb0E", 32), ("k_mc_stepILb1E", 4), ("k_mc_stepILb0E", 4)])
+def test_heads_request_their_inputs_in_one_round_trip(listing, sub, least):
+    """A block's head asks for everything it needs before it waits for any of it ("a head's inputs in
+    ONE memory round trip"): the heads of the lone form of k_gmm_step and the closers of the batch form have a thread's 32 row
+    loads in flight together (round 4's compiler had folded an item's first addition into the branch of its first load, with
+    a wait in front of the other fifteen, and kept the copy loops beside them as load / wait / store: eight dependent round
+    trips in a lone head); an MC block the collision world and the sector table.  Counted in the listing's linear order, so a
+    lower bound of what is in flight.  A property of the emitted ISA that no GPU test would notice going."""
+    ops = kernel(listing, sub)
+    assert _longest_run_of_loads(ops) >= least, (sub, _longest_run_of_loads(ops))
