@@ -386,7 +386,7 @@ __device__ __forceinline__ void speculate_counts(const pocs_gmm_launch& a, int K
 }
 
 // the wave of advance_components, after it (+ barrier): weights, component counts (the speculated ones
-// if there are any and their premise held), write-through stores of state[w] / param[w], drained.
+// if there are any and their premise held), write-through stores of state[w] / param[w].
 __device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, int w, int r, int lane, double* scratch,
                                                const double* spec, const bool publish = true) {
   const adv_ptrs p = advance_ptrs(a, K, w, r, scratch);
@@ -405,7 +405,8 @@ __device__ __forceinline__ void advance_finish(const pocs_gmm_launch& a, int K, 
   if (!publish) return;                              // (lone call: one block of the launch writes the records out)
   for (int j = lane; j < p.ss; j += 64) store_wt(&p.g_state[(size_t)w * p.ss + j], p.l_next[j]);
   for (int j = lane; j < p.ps; j += 64) store_wt(&p.g_param[(size_t)w * p.ps + j], p.l_par[j]);
-  drain_stores();
+  // (not drained: nothing inside this launch reads the records -- state[w] / param[w] are for the NEXT waypoint's launch, behind
+  // the kernel boundary; waiting for the write-through stores here kept every closer 1.2 us longer in the launch's tail)
 }
 
 // The whole advance to waypoint w by a block of >= 128 threads (every thread calls it).
