@@ -188,9 +188,10 @@ int grid_blocks(long long count, int block, int bpc) {
 // run's `chunks` are cut into VS = 2^vs_shift virtual slices -- a function of the shard's sample count
 // ONLY, the moment sums are defined on them -- and the launch's units (run, virtual slice) are dealt to
 // the blocks `upb` at a time.  The chip takes blocks 256 at a time (one more per CU) and holds 512 of
-// these: `upb` is the smallest number that fits the launch into 512 blocks (256 below 8 runs: fewer,
+// these: `upb` is the smallest number that fits the launch into 512 blocks (256 below 4 runs: fewer,
 // fatter blocks amortise head and tail better when the launch is short anyway), so every block of a launch
 // has the same amount of work whatever the number of runs (20 runs x 256 slices = 512 blocks x 10).
+#define POCS_FULL_GRID_FROM_RUNS 4   // (round 4, measured after the heads got shorter: 512 blocks from 4 runs per launch on, +4 % at 4 runs, +6-7 % at 6 and 7; 2 and 3 runs lose 4 % with them -- profiles/r04_ab_full_grid_from_4_runs.txt; it was 8)
 struct GmmGeometry { long long chunks; int vs_shift; int upb; int blocks; };
 GmmGeometry gmm_geometry(long long count, int runs, int K, int groups = 1) {
   const int tb = POCS_GMM_BLOCK_OF(K);
@@ -203,7 +204,7 @@ GmmGeometry gmm_geometry(long long count, int runs, int K, int groups = 1) {
   if (runs < 1) runs = 1;
   const long long units = (long long)runs << g.vs_shift;
   // (`groups` launches share the chip: each gets its share of the resident blocks)
-  const long long budget = (runs * groups >= 8 ? POCS_NUM_CUS * POCS_GMM_BLOCKS_PER_CU : POCS_NUM_CUS) / groups;
+  const long long budget = (runs * groups >= POCS_FULL_GRID_FROM_RUNS ? POCS_NUM_CUS * POCS_GMM_BLOCKS_PER_CU : POCS_NUM_CUS) / groups;
   g.upb = (int)((units + budget - 1) / budget);
   if (g.upb > (1 << g.vs_shift)) g.upb = 1 << g.vs_shift;           // a block's range touches at most two runs
   g.blocks = (int)((units + g.upb - 1) / g.upb);
