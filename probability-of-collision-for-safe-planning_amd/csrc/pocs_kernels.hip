@@ -1114,7 +1114,9 @@ __global__ __launch_bounds__(TB, (LONE ? 1 : POCS_GMM_BLOCKS_PER_CU) * TB / 256)
     // (the cull of the obstacle table against the mixture of waypoint w -- means and factors only -- by wave 1, beside wave 0's
     // normalisation and publishing instead of behind them and a barrier)
     auto cull_early = [&]() __attribute__((always_inline)) { gmm_cull(a, sm, 0, tid - 64, ap.l_par); };
+    if (tid < 128) __builtin_amdgcn_s_setprio(3);          // the components' chain and the count lane go first on their SIMDs; the drawing waves fill in
     advance_block(a, K, w, r0, sm.adv(), sm.spec(), true, tid, TB, true, out, draw_ahead, cull_early);
+    if (tid < 128) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     POCS_STAMP(6);
     POCS_STAMP_COUNT(14);
